@@ -1,0 +1,465 @@
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Run only in the build container (``/root/reference`` present):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+
+The reference is imported read-only (``sys.dont_write_bytecode``); its one
+missing dependency on the orchestrator path, ``nibabel``, is replaced by a
+no-op stand-in module.  Only inputs and outputs (data)
+are written; no reference source travels.  Fixtures: G1..G10 of SURVEY.md 8(c).
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/src"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+torch.set_num_threads(8)
+
+_nib = types.ModuleType("nibabel")
+
+
+class _Nii:
+    def __init__(self, *a, **k):
+        pass
+
+    def to_filename(self, f):
+        pass
+
+
+_nib.Nifti1Image, _nib.load = _Nii, (lambda f: None)
+sys.modules["nibabel"] = _nib
+
+import models  # noqa: E402
+from models import layer_helper, solver, fold_bn, factoryQ, factory_blk  # noqa: E402
+from models.PTQConv import PTQConv  # noqa: E402
+import definer  # noqa: E402
+import ptqer  # noqa: E402
+
+EQ_MOD = sys.modules["models.EfficientQConv"]
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path)/1024:.1f} KB")
+
+
+def relu_gauss(gen, *shape):
+    return torch.relu(torch.randn(*shape, generator=gen))
+
+
+# ---------------------------------------------------------------- G1 discretize
+def g1():
+    gen = torch.Generator().manual_seed(101)
+    out = {}
+    for L in (4, 16, 256):
+        for (lo, hi) in ((-1, 1), (0, 1)):
+            d = (hi - lo) / (L - 1)
+            v = torch.randn(3072, generator=gen) * 0.8
+            # exact half-way points between levels, level points, and out of range
+            k = torch.arange(0, min(L, 256) - 1, dtype=torch.float32)
+            half = (k + 0.5) * d + lo
+            lev = k * d + lo
+            extra = torch.tensor([lo - 1.5, hi + 2.0, lo, hi, 0.0, -0.0, 1e-8, -1e-8])
+            v = torch.cat([v, half, lev, extra])[:4096].contiguous()
+            q32 = layer_helper.discretize(v, L, lo, hi)
+            q64 = layer_helper.discretize(v.double(), L, lo, hi)
+            tag = f"L{L}_{'w' if lo < 0 else 'a'}"
+            out[f"{tag}_in"] = v
+            out[f"{tag}_q32"] = q32
+            out[f"{tag}_q64"] = q64
+            # PTQConv._quantize_act style: x/alpha then *alpha (fp32), PTQConv.py:114-116
+            alpha = torch.tensor(0.7341)
+            out[f"{tag}_qdq32"] = layer_helper.discretize(v / alpha, L, lo, hi) * alpha
+    save("g1_discretize.npz", **out)
+
+
+# ---------------------------------------------------------------- G2 project_by_iter
+def g2():
+    gen = torch.Generator().manual_seed(202)
+    out = {}
+    act = relu_gauss(gen, 2, 8, 16, 16, 16)
+    wgt = torch.randn(16, 16, 3, 3, 3, generator=gen) * 0.05
+    out["act"] = act
+    out["wgt"] = wgt
+    for L in (4, 16, 256):
+        cnt = {"n": 0}
+        orig = layer_helper.discretize
+
+        def counting(*a, **k):
+            cnt["n"] += 1
+            return orig(*a, **k)
+
+        layer_helper.discretize = counting
+        try:
+            a, b = layer_helper.project_by_iter(act, L, 0, 1)
+            out[f"act_L{L}_alpha"] = np.float64(a)
+            out[f"act_L{L}_iters"] = np.int64(cnt["n"] - 1)
+            out[f"act_L{L}_idx"] = torch.round(b * (L - 1)).to(torch.uint8)
+            out[f"act_L{L}_b"] = b if L <= 16 else b[:1, :1]
+            cnt["n"] = 0
+            a, b = layer_helper.project_by_iter(wgt, L, -1, 1)
+            out[f"wgt_L{L}_alpha"] = np.float64(a)
+            out[f"wgt_L{L}_iters"] = np.int64(cnt["n"] - 1)
+            out[f"wgt_L{L}_idx"] = torch.round((b + 1) * (L - 1) / 2).to(torch.uint8)
+        finally:
+            layer_helper.discretize = orig
+    save("g2_project.npz", **out)
+
+
+# ---------------------------------------------------------------- G3 Gram, G4 solve
+def g3_g4():
+    gen = torch.Generator().manual_seed(303)
+    out = {}
+    cases = [
+        ("k3s1p1", 3, 1, 1, True, True),
+        ("k3s221p1", 3, (2, 2, 1), 1, True, True),
+        ("k1s1p0", 1, 1, 0, True, False),
+        ("k3s1p1_nobias_noatt", 3, 1, 1, False, False),
+    ]
+    for tag, k, s, p, has_b, has_att in cases:
+        N, c1, c2 = 2, 3, 5
+        x = relu_gauss(gen, N, c1, 5, 6, 7)
+        w = torch.randn(c2, c1, k, k, k, generator=gen) * 0.2
+        b = torch.randn(c2, generator=gen) * 0.1 if has_b else None
+        y = F.conv3d(x, w, b, s, p) + 0.05 * torch.randn(
+            F.conv3d(x, w, b, s, p).shape, generator=gen)
+        att = torch.randint(1, 4, y[:, 0].shape, generator=gen).float() if has_att else None
+        qs = solver.QuadraSolver(x, y, k, k, k, s, p, device="cpu", mu=0, eta=1.3, W0=w.clone(),
+                                 att=att, b0=b.clone() if has_b else None)
+        out[f"{tag}_x"], out[f"{tag}_y"], out[f"{tag}_w"] = x, y, w
+        if has_b:
+            out[f"{tag}_b"] = b
+        if has_att:
+            out[f"{tag}_att"] = att
+        out[f"{tag}_A0"], out[f"{tag}_B0"] = qs.A0, qs.B0
+        G = w + 0.01 * torch.randn(w.shape, generator=gen)
+        out[f"{tag}_G"] = G
+        res = qs.solve(7.5, 1.3, G)
+        if has_b:
+            out[f"{tag}_wstar"], out[f"{tag}_bstar"] = res
+        else:
+            out[f"{tag}_wstar"] = res
+    save("g3g4_gram_solve.npz", **out)
+
+
+# ---------------------------------------------------------------- G5 one layer ptq
+def run_layer(c1, c2, k, stride, pad, N, S, L_w, L_a, q_act, seed, with_mask, bias=True):
+    gen = torch.Generator().manual_seed(seed)
+    conv = models.EfficientQConv(c1, c2, k, stride, pad, 1, 1, bias, q_weight=True, qlvl=L_w,
+                                 q_act=q_act, qlvl_act=L_a)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (1.0 / (c1 * k ** 3) ** 0.5))
+        if bias:
+            conv.bias.copy_(torch.randn(c2, generator=gen) * 0.1)
+    x_fp = relu_gauss(gen, N, c1, S, S, S)
+    conv.set_fp()
+    y = conv(x_fp).detach()
+    # quantised-upstream stand-in: perturbed input (quirk Q9)
+    x = torch.relu(x_fp + 0.05 * torch.randn(x_fp.shape, generator=gen))
+    conv.output_fp = y
+    conv.name = f"layer_c{c1}_{c2}_k{k}"
+    conv.layer_loss = []
+    if with_mask:
+        m_full = torch.randint(1, 4, y[:, 0].shape, generator=gen).float()
+        m_half = torch.ones(N, *[d // 2 for d in y.shape[2:]])
+        conv.mask_pyramid = [m_half, m_full]
+    w_in, b_in = conv.weight.data.clone(), (conv.bias.data.clone() if bias else None)
+
+    losses, alphas = [], []
+    orig_mse, orig_proj = F.mse_loss, EQ_MOD.project_by_iter
+
+    def mse_spy(*a, **kw):
+        r = orig_mse(*a, **kw)
+        losses.append(r.item())
+        return r
+
+    def proj_spy(v, L, lo=-1., hi=1.):
+        a, b = orig_proj(v, L, lo, hi)
+        alphas.append((lo, a))
+        return a, b
+
+    F.mse_loss, EQ_MOD.project_by_iter = mse_spy, proj_spy
+    try:
+        with torch.no_grad():
+            conv.ptq(x)
+    finally:
+        F.mse_loss, EQ_MOD.project_by_iter = orig_mse, orig_proj
+    aw_hist = np.array([a for lo, a in alphas if lo < 0], dtype=np.float64)
+    rec = dict(x=x, y=y, w_in=w_in, loss_hist=np.array(losses[:200], dtype=np.float64),
+               final_mse=np.float64(losses[200]), aw_hist=aw_hist,
+               weight=conv.weight.data, alpha_w=conv.alpha_w.data, alpha_act=conv.alpha_act.data,
+               layer_loss=np.float64(float(conv.layer_loss[0].split(":")[1])),
+               meta=np.array([c1, c2, k, pad, N, S, L_w, L_a, int(q_act), int(with_mask)]),
+               stride=np.array(solver.triplet(stride)))
+    if bias:
+        rec["b_in"] = b_in
+        rec["bias"] = conv.bias.data
+    if with_mask:
+        rec["mask_full"] = m_full
+    # the forward that feeds the next layer (PTQConv.py:157-162)
+    conv.set_quantized()
+    rec["fwd_q"] = conv(x).detach()
+    return rec
+
+
+def g5():
+    out = {}
+    for tag, kw in {
+        "L4": dict(c1=8, c2=8, k=3, stride=1, pad=1, N=2, S=12, L_w=4, L_a=4, q_act=True, seed=505,
+                   with_mask=True),
+        "L16": dict(c1=8, c2=8, k=3, stride=1, pad=1, N=2, S=12, L_w=16, L_a=16, q_act=True, seed=506,
+                    with_mask=False),
+        "first": dict(c1=2, c2=8, k=3, stride=2, pad=1, N=2, S=12, L_w=256, L_a=256, q_act=False,
+                      seed=507, with_mask=True),
+        "k1": dict(c1=8, c2=16, k=1, stride=1, pad=0, N=2, S=8, L_w=4, L_a=4, q_act=True, seed=508,
+                   with_mask=False),
+    }.items():
+        rec = run_layer(**kw)
+        for k, v in rec.items():
+            out[f"{tag}_{k}"] = v
+        print(tag, "layer_loss", rec["layer_loss"], "best", int(np.argmin(rec["loss_hist"])))
+    save("g5_layer_ptq.npz", **out)
+
+
+# ---------------------------------------------------------------- G6 whole do_ptq
+def tiny_args(task, L, S, nmod, ncls, multi_label=None, init_stride="1", width="8,16,8",
+              depth="1,1,1", root="/tmp/effq_gold"):
+    return argparse.Namespace(
+        pretrain=f"{root}/round1_fp.pkl", resume=None, device="cpu", task=task, round="1", suffix="",
+        config=None, test_fp=False, no_test=True, save_nii=False, bin_label=None,
+        multi_label=multi_label, model="UResQ", nMod=nmod, nClass=ncls, init_stride=init_stride,
+        width=width, depth=depth, dilation=None, nla="relu", norm="bn", drop_rate=0.5, ds="simple",
+        init_kernel=3, hetero_dim=True, blk="mid", qconv="effq", qlvl_w=L, qlvl_a=L,
+        q_first="256,-1", q_last="256,-1", lwq_dataid=0, lwq_batchsz=2,
+        lwq_patchsz=f"{S},{S},{S}", lwq_verbose=False)
+
+
+def randomise(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, nn.Conv3d):
+                fan = m.weight[0].numel()
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan) ** 0.5)
+                if m.bias is not None:
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.05)
+            if isinstance(m, nn.BatchNorm3d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+
+
+def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False):
+    root = "/tmp/effq_gold"
+    os.makedirs(root + "/snap", exist_ok=True)
+    if task == "lits":
+        args = tiny_args("lits", L, S, 1, 3)
+    else:
+        args = tiny_args("brats", L, S, 2, 4, multi_label="brats", init_stride="2,2,2")
+    QConv, Qinfo, kwQ = definer.get_conv_class(args)
+    mc, _ = definer.get_model_cube(args, QConv, kwQ)
+    model = mc["model"]
+    randomise(model, 606)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.save({"state_dict": model.state_dict()}, args.pretrain)
+    nmod = args.nMod
+    g = torch.Generator().manual_seed(1)
+    vols = torch.randn(2, nmod, S, S, S, generator=g)
+    if task == "brats":
+        zz = torch.arange(S).float() - (S - 1) / 2
+        r = (zz[:, None, None] ** 2 + zz[None, :, None] ** 2 + zz[None, None, :] ** 2).sqrt()
+        vols = vols * (r < 0.45 * S).float()
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(s):
+            return 2
+
+        def __getitem__(s, i):
+            return vols[i], torch.zeros(S, S, S).long()
+
+        def use_fix_transform(s):
+            pass
+
+    cube = types.SimpleNamespace(trainseqloader=torch.utils.data.DataLoader(DS(), 1, shuffle=False))
+    captured = {}
+    orig_set_mask = ptqer.set_mask
+
+    def spy_set_mask(m, pyr):
+        captured["pyr"] = [p.clone() for p in pyr]
+        return orig_set_mask(m, pyr)
+
+    ptqer.set_mask = spy_set_mask
+
+    def snap(name, compress=False):
+        captured[name] = {k: v.clone() for k, v in model.state_dict().items()}
+
+    tester = types.SimpleNamespace(test_as_is=lambda *a, **k: None, snapshot=snap)
+    # capture output_q / output_fp through extract_nii
+    outs = []
+    orig_extract = ptqer.extract_nii
+
+    def spy_extract(o, task="lits"):
+        outs.append(o.detach().clone())
+        return orig_extract(o, task=task)
+
+    ptqer.extract_nii = spy_extract
+    try:
+        ptqer.do_ptq(args, mc, cube, tester, root + "/snap")
+    finally:
+        ptqer.set_mask, ptqer.extract_nii = orig_set_mask, orig_extract
+    with open(root + "/snap/layer_loss.txt") as f:
+        ll = f.read().strip().split("\n")
+    with open(root + "/snap/class_voxel_nums.txt") as f:
+        nums = [int(float(t)) for t in f.read().split()]
+    sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4), slice(None, None, 4))
+    out = {"vols_seed": np.int64(1), "vols_check": vols[:, :, ::8, ::8, ::8],
+           "output_q_sub": outs[0][-1][sub], "output_fp_sub": outs[1][-1][sub],
+           "output_q_stats": np.array([outs[0][-1].double().mean().item(), outs[0][-1].double().std().item()]),
+           "output_fp_stats": np.array([outs[1][-1].double().mean().item(), outs[1][-1].double().std().item()]),
+           "agree": np.float64(((outs[0][-1] > 0) == (outs[1][-1] > 0)).float().mean().item()),
+           "layer_names": np.array([l.split(":")[0].strip() for l in ll]),
+           "layer_loss": np.array([float(l.split(":")[1]) for l in ll], dtype=np.float64),
+           "class_nums": np.array(nums, dtype=np.int64),
+           "meta": np.array([L, S])}
+    with open(root + "/snap/time_cost.txt") as f:
+        print("reference time_cost:", f.read())
+    for i, p in enumerate(captured["pyr"]):
+        out[f"pyr{i}"] = p.to(torch.uint8)
+        assert (p == p.to(torch.uint8).float()).all()
+    for k, v in sd0.items():
+        out["sd0/" + k] = v
+    for k, v in captured["state_in_fp.pkl"].items():
+        out["sdq/" + k] = v
+    for k, v in captured["state_in_int8.pkl"].items():
+        if k.endswith(".weight") and v.dtype == torch.uint8:
+            out["sdi/" + k] = v
+    save(tag + ".npz", **out)
+    print("\n".join(ll))
+
+
+# ---------------------------------------------------------------- G7 BN fold
+def g7():
+    gen = torch.Generator().manual_seed(707)
+    blk = factoryQ.NLAConvBN_3d(4, 6, 3, 1, 1, 1, bias=False)
+    randomise(blk, 708)
+    blk.eval()
+    x = torch.randn(2, 4, 6, 6, 6, generator=gen)
+    w0 = blk.conv.weight.data.clone()
+    bn = blk.bn
+    rec = dict(x=x, w=w0, gamma=bn.weight.data.clone(), beta=bn.bias.data.clone(),
+               mean=bn.running_mean.clone(), var=bn.running_var.clone(), eps=np.float64(bn.eps),
+               y_before=blk(x.clone()).detach())
+    fold_bn.search_fold_and_remove_bn(blk)
+    rec.update(w_fold=blk.conv.weight.data.clone(), b_fold=blk.conv.bias.data.clone(),
+               y_after=blk(x.clone()).detach())
+    save("g7_bnfold.npz", **rec)
+
+
+# ---------------------------------------------------------------- G8 att map / pyramid
+def g8():
+    gen = torch.Generator().manual_seed(808)
+    out = {}
+    for task, C in (("lits", 3), ("brats", 3)):
+        logits = torch.randn(3, 2, C, 8, 8, 8, generator=gen) * 2
+        if task == "lits":
+            logits[:, :, 0] += 1.5
+        data = torch.randn(2, 2, 8, 8, 8, generator=gen)
+        data[:, :, :2] = 0
+        data[:, :, :, :, 6:] = 0
+        body = (data[:, 0] != 0).bool() if task == "brats" else torch.ones_like(data[:, 0]).bool()
+        wmap, nums = ptqer.get_att_weight_map(logits, torch.ones_like(data[:, 0]).bool(), "p:0.5", task=task)
+        for st in ("1", "2,2,2"):
+            if st != "1":
+                lg = F.interpolate(logits[-1], scale_factor=2, mode="trilinear")[None]
+                dt = F.interpolate(data, scale_factor=2, mode="nearest")
+                bd = (dt[:, 0] != 0).bool() if task == "brats" else torch.ones_like(dt[:, 0]).bool()
+                wm, nm = ptqer.get_att_weight_map(lg, torch.ones_like(dt[:, 0]).bool(), "p:0.5", task=task)
+                pyr = ptqer.get_mask_pyramid(lg, bd, wm, st, num_lvls=3, task=task)
+                key = f"{task}_s2"
+                out[f"{key}_logits"], out[f"{key}_data"] = lg, dt
+            else:
+                wm, nm = wmap, nums
+                pyr = ptqer.get_mask_pyramid(logits, body, wmap, st, num_lvls=3, task=task)
+                key = f"{task}_s1"
+                out[f"{key}_logits"], out[f"{key}_data"] = logits, data
+            out[f"{key}_nums"] = np.array(nm, dtype=np.int64)
+            out[f"{key}_wvals"] = np.array([wm[i] for i in range(len(wm))], dtype=np.float64)
+            for i, p in enumerate(pyr):
+                out[f"{key}_pyr{i}"] = p.to(torch.uint8)
+                assert (p == p.to(torch.uint8).float()).all()
+    save("g8_attmask.npz", **out)
+
+
+# ---------------------------------------------------------------- G9 int storage
+def g9():
+    gen = torch.Generator().manual_seed(909)
+    out = {}
+    for L in (4, 16, 256):
+        conv = PTQConv(4, 6, 3, 1, 1, qlvl=L)
+        a_best = 0.0831
+        idx = torch.randint(0, L, conv.weight.shape, generator=gen)
+        q = a_best * (idx.float() * (2 / (L - 1)) - 1)
+        conv.weight.data = q.clone()
+        conv.alpha_w.data = torch.tensor(a_best * 1.0007)      # mismatched scale (quirk Q6)
+        conv.store_int_weight()
+        stored = conv.weight.data.clone()
+        conv.restore_fp_weight()
+        out[f"L{L}_q"], out[f"L{L}_alpha"] = q, conv.alpha_w.data.clone()
+        out[f"L{L}_int"], out[f"L{L}_restored"] = stored, conv.weight.data.clone()
+    save("g9_intweight.npz", **out)
+
+
+# ---------------------------------------------------------------- G10 ResBlock mid
+def g10():
+    gen = torch.Generator().manual_seed(1010)
+    rb = factory_blk.ResBlockWithType(4, 4, 0.5, 1, factoryQ.ReLU(True), nn.Conv3d, nn.BatchNorm3d, "mid")
+    randomise(rb, 1011)
+    rb.eval()
+    x = torch.randn(2, 4, 6, 6, 6, generator=gen)
+    y = rb(x.clone())
+    rec = {"x": x, "y": y.detach()}
+    for k, v in rb.state_dict().items():
+        rec["sd/" + k] = v
+    save("g10_resblock_mid.npz", **rec)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3g4", "g5", "g6", "g6b", "g7", "g8", "g9", "g10"]
+    with torch.no_grad():
+        if "g1" in which:
+            g1()
+        if "g2" in which:
+            g2()
+        if "g3g4" in which:
+            g3_g4()
+        if "g7" in which:
+            g7()
+        if "g8" in which:
+            g8()
+        if "g9" in which:
+            g9()
+        if "g10" in which:
+            g10()
+    if "g5" in which:
+        g5()
+    if "g6" in which:
+        g6("lits", 4, 32, "g6_tiny_lits_L4")
+    if "g6b" in which:
+        g6("brats", 4, 64, "g6_tiny_brats_L4")

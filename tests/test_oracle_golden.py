@@ -1,0 +1,137 @@
+"""Pins the CPU oracle (oracle/effq_oracle.py) to outputs of the real reference
+(fixtures written by tests/golden/make_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import effq_oracle as O
+
+T = torch.from_numpy
+
+
+def test_g1_discretize_bit_exact(gold):
+    g = gold("g1_discretize.npz")
+    for L in (4, 16, 256):
+        for tag, lo, hi in (("w", -1, 1), ("a", 0, 1)):
+            v = T(g[f"L{L}_{tag}_in"])
+            assert torch.equal(O.discretize(v, L, lo, hi), T(g[f"L{L}_{tag}_q32"]))
+            assert torch.equal(O.discretize(v.double(), L, lo, hi), T(g[f"L{L}_{tag}_q64"]))
+            alpha = torch.tensor(0.7341)
+            assert torch.equal(O.discretize(v / alpha, L, lo, hi) * alpha, T(g[f"L{L}_{tag}_qdq32"]))
+
+
+def test_g2_fit_scale(gold):
+    g = gold("g2_project.npz")
+    act, wgt = T(g["act"]), T(g["wgt"])
+    for L in (4, 16, 256):
+        fa = O.fit_scale(act, L, 0, 1)
+        assert fa.alpha == float(g[f"act_L{L}_alpha"])
+        assert fa.iters == int(g[f"act_L{L}_iters"])
+        assert torch.equal(torch.round(fa.b * (L - 1)).to(torch.uint8), T(g[f"act_L{L}_idx"]))
+        fw = O.fit_scale(wgt, L, -1, 1)
+        assert fw.alpha == float(g[f"wgt_L{L}_alpha"])
+        assert fw.iters == int(g[f"wgt_L{L}_iters"])
+        assert torch.equal(torch.round((fw.b + 1) * (L - 1) / 2).to(torch.uint8), T(g[f"wgt_L{L}_idx"]))
+
+
+def test_fit_scale_raises_on_cap():
+    # alternating two-cycle cannot be forced cheaply; cap=100*L is hit with tol=0
+    v = torch.randn(257)
+    with pytest.raises(RuntimeWarning):
+        O.fit_scale(v, 4, -1, 1, tol=-1.0)
+
+
+CASES = [("k3s1p1", 3, 1, 1), ("k3s221p1", 3, (2, 2, 1), 1), ("k1s1p0", 1, 1, 0),
+         ("k3s1p1_nobias_noatt", 3, 1, 1)]
+
+
+@pytest.mark.parametrize("tag,k,s,p", CASES)
+def test_g3_g4_gram_and_solve(gold, tag, k, s, p):
+    g = gold("g3g4_gram_solve.npz")
+    x, y, w = T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), T(g[f"{tag}_w"])
+    b = T(g[f"{tag}_b"]) if f"{tag}_b" in g else None
+    att = T(g[f"{tag}_att"]) if f"{tag}_att" in g else None
+    ps = O.ProxSystem(x, y, (k, k, k), s, p, w.clone(), b.clone() if b is not None else None, att)
+    assert torch.equal(ps.A0, T(g[f"{tag}_A0"]))
+    assert torch.equal(ps.B0, T(g[f"{tag}_B0"]))
+    ws, bs = ps.solve(7.5, 1.3, T(g[f"{tag}_G"]))
+    assert torch.equal(ws, T(g[f"{tag}_wstar"]))
+    if b is not None:
+        assert torch.equal(bs, T(g[f"{tag}_bstar"]))
+
+
+def test_patch_matrix_is_conv(gold):
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 6, 7, 5, generator=gen)
+    w = torch.randn(4, 3, 3, 3, 3, generator=gen)
+    cols = torch.from_numpy(O.patch_matrix(x.numpy(), (3, 3, 3), (2, 1, 1), (1, 1, 1)))
+    ref = F.conv3d(x, w, None, (2, 1, 1), 1)
+    got = (w.reshape(4, -1) @ cols).reshape(4, 2, *ref.shape[2:]).transpose(0, 1)
+    assert torch.allclose(got, ref, atol=1e-4)
+
+
+def test_g7_bn_fold(gold):
+    g = gold("g7_bnfold.npz")
+    w2, b2 = O.fold_bn_params(T(g["w"]), None, T(g["gamma"]), T(g["beta"]), T(g["mean"]), T(g["var"]),
+                              float(g["eps"]))
+    assert torch.equal(w2, T(g["w_fold"]))
+    assert torch.equal(b2, T(g["b_fold"]))
+    y = F.conv3d(torch.relu(T(g["x"])), w2, b2, 1, 1)
+    assert torch.equal(y, T(g["y_after"]))
+    assert torch.allclose(y, T(g["y_before"]), atol=1e-5)
+
+
+@pytest.mark.parametrize("task", ["lits", "brats"])
+def test_g8_attention_masks(gold, task):
+    g = gold("g8_attmask.npz")
+    for key, st in ((f"{task}_s1", 1), (f"{task}_s2", (2, 2, 2))):
+        logits, data = T(g[f"{key}_logits"]), T(g[f"{key}_data"])
+        ones = torch.ones_like(data[:, 0]).bool()
+        body = (data[:, 0] != 0).bool() if task == "brats" else ones
+        wmap, nums = O.class_weights(logits[-1], ones, task)
+        assert nums == g[f"{key}_nums"].tolist()
+        assert [wmap[i] for i in range(len(wmap))] == g[f"{key}_wvals"].tolist()
+        pyr = O.mask_pyramid(logits[-1], body, wmap, st, 3, task)
+        for i, m in enumerate(pyr):
+            assert torch.equal(m, T(g[f"{key}_pyr{i}"]).float())
+
+
+def test_g9_int_weight_roundtrip(gold):
+    g = gold("g9_intweight.npz")
+    for L in (4, 16, 256):
+        q, a = T(g[f"L{L}_q"]), T(g[f"L{L}_alpha"])
+        idx = O.weight_to_levels(q, a, L)
+        assert torch.equal(idx, T(g[f"L{L}_int"]))
+        assert torch.equal(O.levels_to_weight(idx, a, L), T(g[f"L{L}_restored"]))
+
+
+def _g5_case(g, tag):
+    c1, c2, k, pad, N, S, L_w, L_a, q_act, with_mask = [int(v) for v in g[f"{tag}_meta"]]
+    stride = tuple(int(v) for v in g[f"{tag}_stride"])
+    x, y, w = T(g[f"{tag}_x"]).clone(), T(g[f"{tag}_y"]).clone(), T(g[f"{tag}_w_in"]).clone()
+    b = T(g[f"{tag}_b_in"]).clone()
+    pyr = None
+    if with_mask:
+        pyr = [torch.ones(N, *[d // 2 for d in y.shape[2:]]), T(g[f"{tag}_mask_full"]).clone()]
+    return dict(x=x, y_fp=y, weight=w, bias=b, stride=stride, padding=pad, qlvl_w=L_w, qlvl_act=L_a,
+                q_act=bool(q_act), mask_pyramid=pyr)
+
+
+@pytest.mark.parametrize("tag", ["L4", "L16", "first", "k1"])
+def test_g5_layer_calibration_bit_exact(gold, tag):
+    g = gold("g5_layer_ptq.npz")
+    kw = _g5_case(g, tag)
+    res = O.calibrate_layer(**kw)
+    assert np.array_equal(np.array(res.loss_history), g[f"{tag}_loss_hist"])
+    assert np.array_equal(np.array(res.alpha_w_history), g[f"{tag}_aw_hist"])
+    assert torch.equal(res.weight, T(g[f"{tag}_weight"]))
+    assert torch.equal(res.bias, T(g[f"{tag}_bias"]))
+    assert np.float32(res.alpha_w) == g[f"{tag}_alpha_w"]
+    if kw["q_act"]:
+        assert np.float32(res.alpha_act) == g[f"{tag}_alpha_act"]
+    assert res.layer_loss == float(g[f"{tag}_layer_loss"])
+    # the quantised forward that feeds the next layer (PTQConv.py:163-167)
+    fwd = O.quantized_forward(kw["x"], res.weight, res.bias, torch.tensor(np.float32(res.alpha_act or 1.0)),
+                              kw["qlvl_act"], kw["q_act"], kw["stride"], kw["padding"])
+    assert torch.equal(fwd, T(g[f"{tag}_fwd_q"]))
