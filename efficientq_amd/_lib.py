@@ -1,0 +1,95 @@
+"""ctypes binding of the C-ABI library ``libeffq_hip.so`` (include/effq_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call
+returns a non-zero status this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeffq_hip.so")
+
+EFFQ_OK = 0
+_ERR_NAMES = {1: "EFFQ_ERR_ARG", 2: "EFFQ_ERR_HIP", 3: "EFFQ_ERR_WORKSPACE", 4: "EFFQ_ERR_NO_DEVICE",
+              5: "EFFQ_ERR_NOT_CONVERGED"}
+
+
+class EffqError(RuntimeError):
+    pass
+
+
+class Geom(C.Structure):
+    """effq_geom of include/effq_hip.h."""
+    _fields_ = [(n, C.c_int32) for n in
+                ("N", "C1", "C2", "D", "H", "W", "KD", "KH", "KW", "SD", "SH", "SW", "PD", "PH", "PW")]
+
+    def out_dims(self):
+        return ((self.D + 2 * self.PD - self.KD) // self.SD + 1,
+                (self.H + 2 * self.PH - self.KH) // self.SH + 1,
+                (self.W + 2 * self.PW - self.KW) // self.SW + 1)
+
+
+class FpState(C.Structure):
+    """effq_fp_state of include/effq_hip.h (48 bytes)."""
+    _fields_ = [("alpha", C.c_double), ("alpha_prev", C.c_double), ("sums", C.c_double * 2),
+                ("iters", C.c_int32), ("done", C.c_int32)]
+
+
+FP_STATE_BYTES = C.sizeof(FpState)
+
+_P, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
+_GP = C.POINTER(Geom)
+
+# name -> (restype, argtypes).  Must list every symbol include/effq_hip.h declares.
+SIGNATURES = {
+    "effq_last_error": (C.c_char_p, []),
+    "effq_version": (_I, []),
+    "effq_device_count": (_I, [C.POINTER(C.c_int)]),
+    "effq_quant_dequant_f32": (_I, [_P, _P, _F, _F, _I, _P, _P, _SZ, _P]),
+    "effq_quant_dequant_f64path": (_I, [_P, _P, _D, _D, _I, _P, _P, _P, _SZ, _P]),
+    "effq_reduce_ws_bytes": (_SZ, []),
+    "effq_abs_sum_f64": (_I, [_P, _SZ, _P, _P, _P]),
+    "effq_moments_f64": (_I, [_P, _SZ, _P, _P, _P]),
+    "effq_alpha_stats_f64": (_I, [_P, _P, _D, _D, _I, _SZ, _P, _P, _P, _P]),
+    "effq_fp_init": (_I, [_P, _P, _P]),
+    "effq_fp_update": (_I, [_P, _D, _I, _P]),
+    "effq_alpha_fixed_point": (_I, [_P, _SZ, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
+    "effq_gram_ws_bytes": (_SZ, [_GP, _I]),
+    "effq_gram_accum": (_I, [_P, _P, _P, _GP, _I, _P, _P, _I, _P, _SZ, _P]),
+    "effq_spd_inverse_ws_bytes": (_SZ, [_I]),
+    "effq_spd_inverse": (_I, [_P, _I, _I, _D, _D, _P, _P, _SZ, _P]),
+    "effq_prox_ws_bytes": (_SZ, [_I, _I]),
+    "effq_prox_solve": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _D, _D, _P, _P, _P, _SZ, _P]),
+    "effq_admm_presum": (_I, [_P, _P, _P, _SZ, _P]),
+    "effq_admm_project_dual": (_I, [_P, _P, _P, _I, _P, _P, _F, _SZ, _P]),
+    "effq_admm_keep_best": (_I, [_P, _P, _I, _P, _P, _P, _P, _SZ, _SZ, _P]),
+    "effq_conv_ws_bytes": (_SZ, [_GP]),
+    "conv3d_quant_calib_step": (_I, [_P, _P, _P, _P, _P, _GP, _P, _I, _P, _P, _P, _SZ, _P]),
+    "effq_adam_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _I, _SZ, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises EffqError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EffqError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"or `make -C efficientq_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != EFFQ_OK:
+        msg = load().effq_last_error().decode(errors="replace")
+        raise EffqError(f"{what} failed with {_ERR_NAMES.get(rc, rc)}: {msg}")

@@ -1,0 +1,131 @@
+// Shared host/device helpers for the effq HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/effq_hip.h"
+
+namespace effq {
+
+void set_error(const char* fmt, ...);
+
+#define EFFQ_CHECK_ARG(cond)                                                        \
+  do {                                                                              \
+    if (!(cond)) {                                                                  \
+      effq::set_error("%s:%d: argument check failed: %s", __FILE__, __LINE__, #cond); \
+      return EFFQ_ERR_ARG;                                                          \
+    }                                                                               \
+  } while (0)
+
+#define EFFQ_HIP(call)                                                                   \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      effq::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return EFFQ_ERR_HIP;                                                               \
+    }                                                                                    \
+  } while (0)
+
+#define EFFQ_LAUNCH_CHECK() EFFQ_HIP(hipGetLastError())
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- reduction workspace -------------------------------------------------------------
+// [0, RED_MAX_BLOCKS*RED_SLOTS) doubles of per-block partials, then one uint32 ticket.
+constexpr int RED_MAX_BLOCKS = 2048;
+constexpr int RED_SLOTS = 4;
+constexpr size_t RED_WS_BYTES = sizeof(double) * RED_MAX_BLOCKS * RED_SLOTS + 256;
+
+struct RedWs {
+  double* partials;
+  unsigned int* ticket;
+};
+static inline RedWs red_ws(void* ws) {
+  RedWs r;
+  r.partials = reinterpret_cast<double*>(ws);
+  r.ticket = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(ws) +
+                                             sizeof(double) * RED_MAX_BLOCKS * RED_SLOTS);
+  return r;
+}
+
+#ifdef __HIPCC__
+// 64-lane wave sum of a double (all lanes end with lane 0's total valid).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Block-wide sum of NS doubles per thread; result valid in thread 0.  smem: NS*16 doubles.
+template <int NS>
+__device__ __forceinline__ void block_sum(double (&v)[NS], double* smem) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) v[s] = wave_sum(v[s]);
+  if (lane == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) smem[s * 16 + wid] = v[s];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      double t = 0.0;
+      for (int w = 0; w < nw; ++w) t += smem[s * 16 + w];
+      v[s] = t;
+    }
+  }
+  __syncthreads();
+}
+
+// Grid-wide deterministic sum: every block publishes NS partials, the block that draws the last
+// ticket adds all partials in block order and writes out[0..NS).  Inter-workgroup hand-off follows
+// the agent-scope release/acquire recipe (cdna_hip_programming.md, Guideline 16): plain stores by
+// one lane -> release fence -> vmcnt(0) -> relaxed agent ticket; last block: acquire fence ->
+// vmcnt(0) -> barrier -> loads.  The ticket is reset by the last block (ws zeroed once at creation).
+template <int NS>
+__device__ __forceinline__ void grid_sum_finish(double (&v)[NS], double* partials, unsigned int* ticket,
+                                                double* out, double* smem, int* s_last,
+                                                unsigned int bid = blockIdx.x, unsigned int nblk = gridDim.x) {
+  block_sum<NS>(v, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) partials[(size_t)bid * NS + s] = v[s];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last = (t == nblk - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (*s_last) {
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+    // fixed assignment of partials to threads + fixed tree => run-to-run deterministic
+    for (unsigned int b = threadIdx.x; b < nblk; b += blockDim.x) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        acc[s] += __hip_atomic_load(&partials[(size_t)b * NS + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    block_sum<NS>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) out[s] = acc[s];
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+#endif  // __HIPCC__
+
+}  // namespace effq

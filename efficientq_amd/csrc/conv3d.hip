@@ -1,0 +1,343 @@
+// conv3d_quant_calib_step: NDHWC implicit-GEMM Conv3d on the f32 matrix cores with an LDS-staged
+// halo tile and a fused squared-error epilogue.
+// Reference: EfficientQConv.py:118-122,161-165 (conv3d + mse per ADMM iteration),
+//            PTQConv.py:154-167 (fp / quantised forward).
+//
+// Mapping (gfx950, wave64): one workgroup = 4 waves = one 4x4x8 block of output voxels (M=128) x
+// (32*NT) output channels.  Wave w owns d-plane w of the block: its 32x32 MFMA tile rows are the
+// 4x8 (h,w) voxels of that plane, columns are 32 output channels.  K runs over (tap, channel):
+// the halo tile of one <=32-channel slab lives in LDS as [voxel][slab+4 pad] floats, so that a
+// ds_read_b128 of 4 channels per lane is bank-conflict free; the lane halves (k index of
+// v_mfma_f32_32x32x2_f32) take channels {0-3} and {4-7} of an 8-channel chunk, giving 4 MFMAs per
+// LDS read.  Weights are repacked once per call into [tap][c/4][c2][4] so that a wave's B operand
+// is one coalesced 16-byte load per lane straight from L2 (shared by every workgroup).
+#include "common.h"
+
+namespace effq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TD = 4, TH = 4, TW = 8;
+
+struct ConvParams {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  const float* y;
+  const float* att;
+  float* out;
+  const float* act_alpha;
+  float act_d;
+  int act_on;
+  int N, C1, C2, D, H, W, OD, OH, OW;
+  int KD, KH, KW, SD, SH, SW, PD, PH, PW;
+  int c1p, c2p, cslab, nslab, CS;
+  int HD, HH, HW, nhalo;
+  int tiles_d, tiles_h, tiles_w, ntiles;
+  double* partials;
+  unsigned int* ticket;
+  double* sqerr;
+};
+
+__device__ __forceinline__ float act_qd(float x, float alpha, float d) {
+  // PTQConv._quantize_act, fp32 (PTQConv.py:114-116): discretize(x/alpha, L, 0, 1) * alpha
+  float t = x / alpha;
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  float r = rintf(t / d);
+  return (r * d) * alpha;
+}
+
+__global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ G, float* __restrict__ wp, int C1,
+                                                     int C2, int T, int c1p, int c2p) {
+  const size_t total = (size_t)T * c1p * c2p;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    int c_lo = (int)(e & 3);
+    size_t r = e >> 2;
+    int j = (int)(r % c2p);
+    r /= c2p;
+    int cq = (int)(r % (c1p / 4));
+    int tap = (int)(r / (c1p / 4));
+    int c = cq * 4 + c_lo;
+    float v = 0.0f;
+    if (c < C1 && j < C2) v = G[((size_t)j * C1 + c) * T + tap];
+    wp[e] = v;
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_conv3d(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // XCD-aware, bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
+  // contiguous run of spatial tiles so neighbouring halos hit the same L2.
+  int tile;
+  {
+    const unsigned bid = blockIdx.x, nwg = (unsigned)p.ntiles;
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, idx = bid >> 3;
+    tile = (int)(xcd * q + (xcd < r ? xcd : r) + idx);
+  }
+  int t = tile;
+  const int tw_i = t % p.tiles_w;
+  t /= p.tiles_w;
+  const int th_i = t % p.tiles_h;
+  t /= p.tiles_h;
+  const int td_i = t % p.tiles_d;
+  const int n = t / p.tiles_d;
+  const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
+  const int id0 = od0 * p.SD - p.PD, ih0 = oh0 * p.SH - p.PH, iw0 = ow0 * p.SW - p.PW;
+  const int ch0 = blockIdx.y * 32 * NT;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+
+  const int HH = p.HH, HW = p.HW, CS = p.CS;
+  const int hv = ((wid * p.SD) * HH + (li >> 3) * p.SH) * HW + (li & 7) * p.SW;
+  const int upv = p.cslab >> 2;
+  const bool vec_ok = (p.C1 & 3) == 0;
+  float alpha = 1.0f;
+  if (p.act_on) alpha = *p.act_alpha;
+
+  for (int s = 0; s < p.nslab; ++s) {
+    __syncthreads();
+    for (int u = tid; u < p.nhalo * upv; u += 256) {
+      const int vox = u / upv, c4 = u - vox * upv;
+      const int hw = vox % HW;
+      const int t2 = vox / HW;
+      const int hh = t2 % HH, hd = t2 / HH;
+      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+      const int c = s * p.cslab + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && c < p.C1) {
+        const float* src = p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 + c;
+        if (vec_ok) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (c + 1 < p.C1) v.y = src[1];
+          if (c + 2 < p.C1) v.z = src[2];
+          if (c + 3 < p.C1) v.w = src[3];
+        }
+        if (p.act_on) {
+          v.x = act_qd(v.x, alpha, p.act_d);
+          v.y = act_qd(v.y, alpha, p.act_d);
+          v.z = act_qd(v.z, alpha, p.act_d);
+          v.w = act_qd(v.w, alpha, p.act_d);
+        }
+      }
+      *reinterpret_cast<float4*>(&lds[vox * CS + c4 * 4]) = v;
+    }
+    __syncthreads();
+
+    const int nq = p.cslab >> 3;
+    for (int kd = 0; kd < p.KD; ++kd)
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw) {
+          const int tap = (kd * p.KH + kh) * p.KW + kw;
+          const float* arow = lds + (hv + (kd * HH + kh) * HW + kw) * CS + 4 * lh;
+          const float* wrow =
+              p.wp + ((size_t)(tap * (p.c1p >> 2) + ((s * p.cslab) >> 2) + lh) * p.c2p + ch0 + li) * 4;
+          for (int q = 0; q < nq; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + q * 8);
+            float4 b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              b[nt] = *reinterpret_cast<const float4*>(wrow + ((size_t)(2 * q) * p.c2p + nt * 32) * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[nt].x, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[nt].y, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[nt].z, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nt].w, acc[nt], 0, 0, 0);
+          }
+        }
+  }
+
+  // ---- epilogue: bias, optional store, fused squared error --------------------------------
+  double l0 = 0.0, l1 = 0.0;
+  const int od = od0 + wid;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ch = ch0 + nt * 32 + li;
+    const bool chok = ch < p.C2;
+    const float bv = (p.bias != nullptr && chok) ? p.bias[ch] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int oh = oh0 + (i >> 3), ow = ow0 + (i & 7);
+      if (chok && od < p.OD && oh < p.OH && ow < p.OW) {
+        const size_t vo = (((size_t)n * p.OD + od) * p.OH + oh) * p.OW + ow;
+        const float o = acc[nt][r] + bv;
+        if (p.out != nullptr) p.out[vo * p.C2 + ch] = o;
+        if (p.y != nullptr) {
+          const float dlt = o - p.y[vo * p.C2 + ch];
+          const float sq = dlt * dlt;
+          l0 += (double)sq;
+          l1 += (p.att != nullptr) ? (double)(p.att[vo] * sq) : (double)sq;
+        }
+      }
+    }
+  }
+  if (p.y != nullptr) {
+    double v[2] = {l0, l1};
+    grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
+                       gridDim.x * gridDim.y);
+  }
+}
+
+struct ConvPlan {
+  ConvParams p;
+  int nt;
+  dim3 grid;
+  size_t lds_bytes;
+  size_t wp_floats;
+  size_t nblk;
+  int T;
+};
+
+static int make_plan(const effq_geom* g, ConvPlan* pl) {
+  EFFQ_CHECK_ARG(g != nullptr);
+  EFFQ_CHECK_ARG(g->N > 0 && g->C1 > 0 && g->C2 > 0 && g->D > 0 && g->H > 0 && g->W > 0);
+  EFFQ_CHECK_ARG(g->KD >= 1 && g->KH >= 1 && g->KW >= 1 && g->KD <= 7 && g->KH <= 7 && g->KW <= 7);
+  EFFQ_CHECK_ARG(g->SD >= 1 && g->SH >= 1 && g->SW >= 1 && g->PD >= 0 && g->PH >= 0 && g->PW >= 0);
+  ConvParams& p = pl->p;
+  memset(&p, 0, sizeof(p));
+  p.N = g->N; p.C1 = g->C1; p.C2 = g->C2; p.D = g->D; p.H = g->H; p.W = g->W;
+  p.KD = g->KD; p.KH = g->KH; p.KW = g->KW; p.SD = g->SD; p.SH = g->SH; p.SW = g->SW;
+  p.PD = g->PD; p.PH = g->PH; p.PW = g->PW;
+  p.OD = (g->D + 2 * g->PD - g->KD) / g->SD + 1;
+  p.OH = (g->H + 2 * g->PH - g->KH) / g->SH + 1;
+  p.OW = (g->W + 2 * g->PW - g->KW) / g->SW + 1;
+  EFFQ_CHECK_ARG(p.OD > 0 && p.OH > 0 && p.OW > 0);
+  p.c1p = (g->C1 + 7) / 8 * 8;
+  p.c2p = (g->C2 + 31) / 32 * 32;
+  p.HD = (TD - 1) * p.SD + p.KD;
+  p.HH = (TH - 1) * p.SH + p.KH;
+  p.HW = (TW - 1) * p.SW + p.KW;
+  p.nhalo = p.HD * p.HH * p.HW;
+  // channel slab: largest of 32/16/8 that divides c1p and keeps the halo tile within 64 KiB of LDS
+  // (two workgroups per CU); fall back to anything that fits the 160 KiB of one CU.
+  int cslab = 0;
+  const int cands[3] = {32, 16, 8};
+  for (int pass = 0; pass < 2 && cslab == 0; ++pass)
+    for (int i = 0; i < 3; ++i) {
+      const int c = cands[i];
+      if (c > p.c1p || p.c1p % c != 0) continue;
+      const size_t bytes = (size_t)p.nhalo * (c + 4) * sizeof(float);
+      if (bytes <= (pass == 0 ? (size_t)64 * 1024 : (size_t)150 * 1024)) {
+        cslab = c;
+        break;
+      }
+    }
+  if (cslab == 0) {
+    set_error("conv3d: halo tile of %d voxels does not fit LDS", p.nhalo);
+    return EFFQ_ERR_ARG;
+  }
+  p.cslab = cslab;
+  p.nslab = p.c1p / cslab;
+  p.CS = cslab + 4;
+  pl->lds_bytes = (size_t)p.nhalo * p.CS * sizeof(float);
+  p.tiles_d = (p.OD + TD - 1) / TD;
+  p.tiles_h = (p.OH + TH - 1) / TH;
+  p.tiles_w = (p.OW + TW - 1) / TW;
+  const long long nt_ll = (long long)p.N * p.tiles_d * p.tiles_h * p.tiles_w;
+  EFFQ_CHECK_ARG(nt_ll < (1ll << 30));
+  p.ntiles = (int)nt_ll;
+  const int nsub = p.c2p / 32;
+  int nt = 4;
+  while (nsub % nt != 0) nt >>= 1;
+  // keep the chip busy on small (deep) layers: prefer more workgroups over wider waves
+  while (nt > 1 && (long long)p.ntiles * (nsub / nt) < 1024) nt >>= 1;
+  pl->nt = nt;
+  pl->grid = dim3((unsigned)p.ntiles, (unsigned)(nsub / nt), 1);
+  pl->nblk = (size_t)p.ntiles * (nsub / nt);
+  pl->T = p.KD * p.KH * p.KW;
+  pl->wp_floats = (size_t)pl->T * p.c1p * p.c2p;
+  return EFFQ_OK;
+}
+
+static size_t conv_ws_bytes(const ConvPlan& pl) {
+  return 256 + pl.nblk * 2 * sizeof(double) + pl.wp_floats * sizeof(float) + 256;
+}
+
+}  // namespace effq
+
+using namespace effq;
+
+extern "C" {
+
+size_t effq_conv_ws_bytes(const effq_geom* g) {
+  ConvPlan pl;
+  if (make_plan(g, &pl) != EFFQ_OK) return 0;
+  return conv_ws_bytes(pl);
+}
+
+int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* bias, const float* y_fp,
+                            const float* att, const effq_geom* g, const float* act_alpha_dev, int act_levels,
+                            double* sqerr_out, float* out, void* ws, size_t ws_bytes, void* stream) {
+  EFFQ_CHECK_ARG(xq_ndhwc && G && g && ws);
+  EFFQ_CHECK_ARG(y_fp != nullptr || out != nullptr);
+  EFFQ_CHECK_ARG(y_fp == nullptr || sqerr_out != nullptr);
+  EFFQ_CHECK_ARG(act_alpha_dev == nullptr || act_levels >= 2);
+  ConvPlan pl;
+  int rc = make_plan(g, &pl);
+  if (rc != EFFQ_OK) return rc;
+  if (ws_bytes < conv_ws_bytes(pl)) {
+    set_error("conv3d: workspace %zu < required %zu", ws_bytes, conv_ws_bytes(pl));
+    return EFFQ_ERR_WORKSPACE;
+  }
+  char* base = reinterpret_cast<char*>(ws);
+  ConvParams& p = pl.p;
+  p.ticket = reinterpret_cast<unsigned int*>(base);
+  p.partials = reinterpret_cast<double*>(base + 256);
+  float* wp = reinterpret_cast<float*>(base + 256 + pl.nblk * 2 * sizeof(double));
+  // 16-byte alignment of the packed weights
+  wp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wp) + 15) & ~(uintptr_t)15);
+  p.x = xq_ndhwc;
+  p.wp = wp;
+  p.bias = bias;
+  p.y = y_fp;
+  p.att = att;
+  p.out = out;
+  p.sqerr = sqerr_out;
+  p.act_on = act_alpha_dev != nullptr;
+  p.act_alpha = act_alpha_dev;
+  p.act_d = p.act_on ? (float)(1.0 / (double)(act_levels - 1)) : 1.0f;
+  hipStream_t st = as_stream(stream);
+  if (y_fp != nullptr) EFFQ_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned int), st));
+  {
+    size_t nb = (pl.wp_floats + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)nb), dim3(256), 0, st, G, wp, p.C1, p.C2, pl.T, p.c1p, p.c2p);
+    EFFQ_LAUNCH_CHECK();
+  }
+  const size_t lds = pl.lds_bytes;
+#define EFFQ_CONV_LAUNCH(NTV)                                                                                  \
+  do {                                                                                                         \
+    if (lds > 64 * 1024)                                                                                       \
+      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d<NTV>),                              \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+    hipLaunchKernelGGL(k_conv3d<NTV>, pl.grid, dim3(256), lds, st, p);                                         \
+  } while (0)
+  if (pl.nt == 4)
+    EFFQ_CONV_LAUNCH(4);
+  else if (pl.nt == 2)
+    EFFQ_CONV_LAUNCH(2);
+  else
+    EFFQ_CONV_LAUNCH(1);
+#undef EFFQ_CONV_LAUNCH
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+}  // extern "C"

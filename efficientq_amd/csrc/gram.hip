@@ -1,0 +1,288 @@
+// effq_gram_accum: attention-weighted Gram system of one layer without materialising im2col.
+// Reference: solver.py:86-111 (im2col_loop), :253-257 (ones row), :282-314 (getA0B0).
+//
+// The patch matrix is never built.  Rows of the extended operand E are
+//   [ x rows (tap-major: r = tap*C1 + c) | ones row (bias) | y rows (C2) ]
+// and one symmetric product S = sum_v att_v E(:,v) E(:,v)^T gives everything:
+//   A0 = 2*S[x|1 , x|1],  B0 = 2*S[y , x|1].
+// Work split: 128x128 macro blocks of the upper triangle of S  x  voxel splits (split-K).
+// Each workgroup streams its voxel range in chunks of KC voxels: the two 128-row panels are
+// gathered (coalesced along channels) into LDS as [voxel][row], and the 4 waves run
+// v_mfma_f32_32x32x2_f32 with K = voxels.  Partial blocks go to per-split slabs; a second
+// kernel adds the slabs in fp64 in a fixed order (deterministic), mirrors, scales by 2 and
+// scatters into the reference's (c,kd,kh,kw)+bias row order.
+#include "common.h"
+
+namespace effq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 32;      // voxels per staged chunk
+constexpr int MB = 128;     // macro block rows
+constexpr int PS = MB + 4;  // LDS row stride (floats)
+
+struct GramParams {
+  const float* x;
+  const float* att;
+  const float* y;
+  int N, C1, C2, D, H, W, OD, OH, OW;
+  int KD, KH, KW, SD, SH, SW, PD, PH, PW;
+  int T, RX, hb, E, NB, npairs;
+  long long V;
+  int nsplit;
+  long long vox_per_split;
+  float* slabs;
+};
+
+struct VoxInfo {
+  int n, id0, ih0, iw0;  // input-space origin of the receptive field; n < 0 => voxel out of range
+};
+
+__device__ __forceinline__ float gram_fetch(const GramParams& p, int rkind, int kd, int kh, int kw, int c,
+                                            const VoxInfo& vi, long long v) {
+  // rkind: 0 x row, 1 ones row, 2 y row (c = y channel), 3 padding
+  if (vi.n < 0 || rkind == 3) return 0.0f;
+  if (rkind == 0) {
+    const int id = vi.id0 + kd, ih = vi.ih0 + kh, iw = vi.iw0 + kw;
+    if (id < 0 || id >= p.D || ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return 0.0f;
+    return p.x[((((size_t)vi.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 + c];
+  }
+  if (rkind == 1) return 1.0f;
+  return p.y[(size_t)v * p.C2 + c];
+}
+
+__global__ __launch_bounds__(256) void k_gram(GramParams p) {
+  __shared__ __attribute__((aligned(16))) float panI[KC * PS];
+  __shared__ __attribute__((aligned(16))) float panJ[KC * PS];
+  __shared__ float att_s[KC];
+  __shared__ VoxInfo vox_s[KC];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // decode (I,J) of the upper triangle from the pair index
+  int I = 0, rem = blockIdx.x;
+  while (rem >= p.NB - I) {
+    rem -= p.NB - I;
+    ++I;
+  }
+  const int J = I + rem;
+  const bool diag = (I == J);
+
+  // this thread stages one fixed row of each panel (row_local = tid % 128) for voxels tid/128, +2, ...
+  const int row_local = tid & (MB - 1);
+  const int vv0 = tid >> 7;
+  int kindI, kdI = 0, khI = 0, kwI = 0, cI = 0;
+  int kindJ, kdJ = 0, khJ = 0, kwJ = 0, cJ = 0;
+  auto decode = [&](int r, int& kind, int& kd, int& kh, int& kw, int& c) {
+    if (r < p.RX) {
+      kind = 0;
+      const int tap = r / p.C1;
+      c = r - tap * p.C1;
+      kw = tap % p.KW;
+      const int t2 = tap / p.KW;
+      kh = t2 % p.KH;
+      kd = t2 / p.KH;
+    } else if (p.hb && r == p.RX) {
+      kind = 1;
+    } else if (r < p.E) {
+      kind = 2;
+      c = r - p.RX - p.hb;
+    } else {
+      kind = 3;
+    }
+  };
+  decode(I * MB + row_local, kindI, kdI, khI, kwI, cI);
+  decode(J * MB + row_local, kindJ, kdJ, khJ, kwJ, cJ);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
+
+  const long long v_begin = (long long)blockIdx.y * p.vox_per_split;
+  long long v_end = v_begin + p.vox_per_split;
+  if (v_end > p.V) v_end = p.V;
+  const float* pj = diag ? panI : panJ;
+
+  for (long long v0 = v_begin; v0 < v_end; v0 += KC) {
+    __syncthreads();  // previous chunk fully consumed
+    if (tid < KC) {
+      const long long v = v0 + tid;
+      VoxInfo vi;
+      float a = 0.0f;
+      if (v < v_end) {
+        long long t = v;
+        const int ow = (int)(t % p.OW);
+        t /= p.OW;
+        const int oh = (int)(t % p.OH);
+        t /= p.OH;
+        const int od = (int)(t % p.OD);
+        vi.n = (int)(t / p.OD);
+        vi.id0 = od * p.SD - p.PD;
+        vi.ih0 = oh * p.SH - p.PH;
+        vi.iw0 = ow * p.SW - p.PW;
+        a = (p.att != nullptr) ? p.att[v] : 1.0f;
+      } else {
+        vi.n = -1;
+        vi.id0 = vi.ih0 = vi.iw0 = 0;
+      }
+      vox_s[tid] = vi;
+      att_s[tid] = a;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int vv = vv0; vv < KC; vv += 2) {
+      const VoxInfo vi = vox_s[vv];
+      panI[vv * PS + row_local] = gram_fetch(p, kindI, kdI, khI, kwI, cI, vi, v0 + vv);
+      if (!diag) panJ[vv * PS + row_local] = gram_fetch(p, kindJ, kdJ, khJ, kwJ, cJ, vi, v0 + vv);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < KC / 2; ++s) {
+      const int vv = 2 * s + lh;
+      const float a = panI[vv * PS + wid * 32 + li] * att_s[vv];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const float b = pj[vv * PS + jt * 32 + li];
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[jt], 0, 0, 0);
+      }
+    }
+  }
+
+  float* dst = p.slabs + ((size_t)blockIdx.y * p.npairs + blockIdx.x) * (size_t)(MB * MB);
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      dst[(size_t)(wid * 32 + i) * MB + jt * 32 + li] = acc[jt][r];
+    }
+}
+
+// Sum the split slabs (fp64, fixed order), scale by 2, mirror, scatter to reference order.
+__global__ __launch_bounds__(256) void k_gram_finish(GramParams p, int n, float* __restrict__ A0,
+                                                     float* __restrict__ B0, int accumulate) {
+  const size_t nA = (size_t)n * n, nB = (size_t)p.C2 * n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nA + nB; e += stride) {
+    int ri, rj;
+    float* dst;
+    if (e < nA) {
+      const int a = (int)(e / n), b = (int)(e % n);
+      // reference row a = c*T + tap  ->  internal tap*C1 + c ; bias row -> RX
+      auto to_int = [&](int q) {
+        if (p.hb && q == n - 1) return p.RX;
+        const int c = q / p.T, tap = q - c * p.T;
+        return tap * p.C1 + c;
+      };
+      ri = to_int(a);
+      rj = to_int(b);
+      if (ri > rj) {
+        const int t = ri;
+        ri = rj;
+        rj = t;
+      }
+      dst = A0 + e;
+    } else {
+      const size_t f = e - nA;
+      const int c2 = (int)(f / n), b = (int)(f % n);
+      if (p.hb && b == n - 1)
+        ri = p.RX;
+      else {
+        const int c = b / p.T, tap = b - c * p.T;
+        ri = tap * p.C1 + c;
+      }
+      rj = p.RX + p.hb + c2;
+      dst = B0 + f;
+    }
+    const int I = ri / MB, J = rj / MB;
+    const size_t pidx = (size_t)I * p.NB - (size_t)I * (I - 1) / 2 + (J - I);
+    const size_t off = pidx * (size_t)(MB * MB) + (size_t)(ri - I * MB) * MB + (rj - J * MB);
+    double s = 0.0;
+    for (int k = 0; k < p.nsplit; ++k) s += (double)p.slabs[(size_t)k * p.npairs * (size_t)(MB * MB) + off];
+    const float val = (float)(2.0 * s);
+    *dst = accumulate ? (*dst + val) : val;
+  }
+}
+
+static int gram_plan(const effq_geom* g, int has_bias, GramParams* pp) {
+  EFFQ_CHECK_ARG(g != nullptr);
+  EFFQ_CHECK_ARG(g->N > 0 && g->C1 > 0 && g->C2 > 0 && g->D > 0 && g->H > 0 && g->W > 0);
+  EFFQ_CHECK_ARG(g->KD >= 1 && g->KH >= 1 && g->KW >= 1 && g->SD >= 1 && g->SH >= 1 && g->SW >= 1);
+  GramParams& p = *pp;
+  memset(&p, 0, sizeof(p));
+  p.N = g->N; p.C1 = g->C1; p.C2 = g->C2; p.D = g->D; p.H = g->H; p.W = g->W;
+  p.KD = g->KD; p.KH = g->KH; p.KW = g->KW; p.SD = g->SD; p.SH = g->SH; p.SW = g->SW;
+  p.PD = g->PD; p.PH = g->PH; p.PW = g->PW;
+  p.OD = (g->D + 2 * g->PD - g->KD) / g->SD + 1;
+  p.OH = (g->H + 2 * g->PH - g->KH) / g->SH + 1;
+  p.OW = (g->W + 2 * g->PW - g->KW) / g->SW + 1;
+  EFFQ_CHECK_ARG(p.OD > 0 && p.OH > 0 && p.OW > 0);
+  p.T = p.KD * p.KH * p.KW;
+  p.RX = p.T * p.C1;
+  p.hb = has_bias ? 1 : 0;
+  p.E = p.RX + p.hb + p.C2;
+  p.NB = (p.E + MB - 1) / MB;
+  p.npairs = p.NB * (p.NB + 1) / 2;
+  p.V = (long long)p.N * p.OD * p.OH * p.OW;
+  // split-K: aim at ~4096 workgroups, at least 8 chunks per split, slabs <= 1 GiB
+  long long chunks = (p.V + KC - 1) / KC;
+  long long want = (4096 + p.npairs - 1) / p.npairs;
+  if (want < 1) want = 1;
+  long long max_by_work = chunks / 8;
+  if (max_by_work < 1) max_by_work = 1;
+  long long max_by_mem = ((long long)1 << 30) / ((long long)p.npairs * MB * MB * 4);
+  if (max_by_mem < 1) max_by_mem = 1;
+  long long ns = want;
+  if (ns > max_by_work) ns = max_by_work;
+  if (ns > max_by_mem) ns = max_by_mem;
+  if (ns > 65535) ns = 65535;
+  long long cps = (chunks + ns - 1) / ns;
+  ns = (chunks + cps - 1) / cps;
+  p.nsplit = (int)ns;
+  p.vox_per_split = cps * KC;
+  return EFFQ_OK;
+}
+
+}  // namespace effq
+
+using namespace effq;
+
+extern "C" {
+
+size_t effq_gram_ws_bytes(const effq_geom* g, int has_bias) {
+  GramParams p;
+  if (gram_plan(g, has_bias, &p) != EFFQ_OK) return 0;
+  return (size_t)p.nsplit * p.npairs * (size_t)(MB * MB) * sizeof(float) + 256;
+}
+
+int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc, const effq_geom* g, int has_bias,
+                    float* A0, float* B0, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  EFFQ_CHECK_ARG(x_ndhwc && y_ndhwc && A0 && B0 && ws);
+  GramParams p;
+  int rc = gram_plan(g, has_bias, &p);
+  if (rc != EFFQ_OK) return rc;
+  const size_t need = (size_t)p.nsplit * p.npairs * (size_t)(MB * MB) * sizeof(float);
+  if (ws_bytes < need) {
+    set_error("gram: workspace %zu < required %zu", ws_bytes, need);
+    return EFFQ_ERR_WORKSPACE;
+  }
+  p.x = x_ndhwc;
+  p.att = att;
+  p.y = y_ndhwc;
+  p.slabs = reinterpret_cast<float*>(ws);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_gram, dim3((unsigned)p.npairs, (unsigned)p.nsplit), dim3(256), 0, st, p);
+  EFFQ_LAUNCH_CHECK();
+  const int n = p.RX + p.hb;
+  size_t tot = (size_t)n * n + (size_t)p.C2 * n;
+  size_t nb = (tot + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)nb), dim3(256), 0, st, p, n, A0, B0, accumulate);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+}  // extern "C"

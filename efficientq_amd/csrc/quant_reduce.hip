@@ -1,0 +1,387 @@
+// Quantiser primitives and fp64 statistics (HBM-bound streaming kernels).
+// Reference: layer_helper.py:25-70 (discretize, project_by_iter), PTQConv.py:114-116.
+// All arithmetic follows the reference's operation order with IEEE divisions and no FMA
+// contraction (the library is built with -ffp-contract=off).
+#include <stdarg.h>
+#include "common.h"
+
+namespace effq {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+constexpr int TPB = 256;
+
+static inline int stream_grid(size_t n_vec) {
+  size_t b = (n_vec + TPB - 1) / TPB;
+  if (b < 1) b = 1;
+  if (b > RED_MAX_BLOCKS) b = RED_MAX_BLOCKS;
+  return (int)b;
+}
+
+// ---- scalar quantiser bodies ----------------------------------------------------------
+__device__ __forceinline__ float qd32(float x, float alpha, float lo, float hi, float d, float* idx) {
+  float t = x / alpha;
+  t = fminf(fmaxf(t, lo), hi);
+  // torch.clamp propagates NaN; fmaxf/fminf would drop it
+  t = (x != x) ? x : t;
+  float r = rintf((t - lo) / d);
+  *idx = r;
+  return (r * d + lo) * alpha;
+}
+
+__device__ __forceinline__ double disc64(double x, double alpha, double lo, double hi, double d, double* idx) {
+  double t = x / alpha;
+  t = fmin(fmax(t, lo), hi);
+  double r = rint((t - lo) / d);
+  *idx = r;
+  return r * d + lo;
+}
+
+__global__ __launch_bounds__(TPB) void k_quant_dequant_f32(const float* __restrict__ x,
+                                                           const float* __restrict__ alpha_dev, float lo,
+                                                           float hi, float d, float* __restrict__ y,
+                                                           uint8_t* __restrict__ idx, size_t n) {
+  const float alpha = *alpha_dev;
+  const size_t nv = n / 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    float r0, r1, r2, r3;
+    float4 o;
+    o.x = qd32(v.x, alpha, lo, hi, d, &r0);
+    o.y = qd32(v.y, alpha, lo, hi, d, &r1);
+    o.z = qd32(v.z, alpha, lo, hi, d, &r2);
+    o.w = qd32(v.w, alpha, lo, hi, d, &r3);
+    if (y) reinterpret_cast<float4*>(y)[i] = o;
+    if (idx) {
+      uchar4 u = make_uchar4((unsigned char)r0, (unsigned char)r1, (unsigned char)r2, (unsigned char)r3);
+      reinterpret_cast<uchar4*>(idx)[i] = u;
+    }
+  }
+  // ragged tail
+  for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float r;
+    float o = qd32(x[i], alpha, lo, hi, d, &r);
+    if (y) y[i] = o;
+    if (idx) idx[i] = (unsigned char)r;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_quant_dequant_f64path(const float* __restrict__ x,
+                                                               const double* __restrict__ alpha_dev, double lo,
+                                                               double hi, double d, float* __restrict__ y,
+                                                               float* __restrict__ bout,
+                                                               uint8_t* __restrict__ idx, size_t n) {
+  const double alpha = *alpha_dev;
+  const float alpha32 = (float)alpha;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t nv = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    double r0, r1, r2, r3;
+    float4 b;
+    b.x = (float)disc64((double)v.x, alpha, lo, hi, d, &r0);
+    b.y = (float)disc64((double)v.y, alpha, lo, hi, d, &r1);
+    b.z = (float)disc64((double)v.z, alpha, lo, hi, d, &r2);
+    b.w = (float)disc64((double)v.w, alpha, lo, hi, d, &r3);
+    if (bout) reinterpret_cast<float4*>(bout)[i] = b;
+    if (y) {
+      float4 o = make_float4(alpha32 * b.x, alpha32 * b.y, alpha32 * b.z, alpha32 * b.w);
+      reinterpret_cast<float4*>(y)[i] = o;
+    }
+    if (idx)
+      reinterpret_cast<uchar4*>(idx)[i] =
+          make_uchar4((unsigned char)r0, (unsigned char)r1, (unsigned char)r2, (unsigned char)r3);
+  }
+  for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double r;
+    float b = (float)disc64((double)x[i], alpha, lo, hi, d, &r);
+    if (bout) bout[i] = b;
+    if (y) y[i] = alpha32 * b;
+    if (idx) idx[i] = (unsigned char)r;
+  }
+}
+
+// ---- fp64 reductions ---------------------------------------------------------------------
+// MODE 0: sum|x|, n     MODE 1: sum x, sum x^2, n     MODE 2: sum b*x, sum b*b  (b=discretize(x/alpha))
+template <int MODE>
+__global__ __launch_bounds__(TPB) void k_reduce(const float* __restrict__ x, size_t n,
+                                                const double* __restrict__ alpha_dev, double lo, double hi,
+                                                double d, const int32_t* __restrict__ done_flag,
+                                                double* partials, unsigned int* ticket, double* out) {
+  constexpr int NS = (MODE == 1) ? 3 : 2;
+  __shared__ double smem[NS * 16];
+  __shared__ int s_last;
+  if (MODE == 2 && done_flag != nullptr && *done_flag != 0) return;  // uniform across the grid
+  double acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+  double alpha = 1.0;
+  if (MODE == 2) alpha = *alpha_dev;
+  const size_t nv = n / 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  auto body = [&](float xf) {
+    double v = (double)xf;
+    if (MODE == 0) {
+      acc[0] += fabs(v);
+    } else if (MODE == 1) {
+      acc[0] += v;
+      acc[1] += v * v;
+    } else {
+      double r;
+      double b = disc64(v, alpha, lo, hi, d, &r);
+      acc[0] += b * v;
+      acc[1] += b * b;
+    }
+  };
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    body(v.x);
+    body(v.y);
+    body(v.z);
+    body(v.w);
+  }
+  for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) body(x[i]);
+  if (MODE != 2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) acc[NS - 1] = (double)n;
+  }
+  grid_sum_finish<NS>(acc, partials, ticket, out, smem, &s_last);
+}
+
+__global__ void k_fp_init(effq_fp_state* st, const double* abs_sums) {
+  st->alpha = abs_sums[0] / abs_sums[1];
+  st->alpha_prev = -999.0;
+  st->sums[0] = 0.0;
+  st->sums[1] = 0.0;
+  st->iters = 0;
+  st->done = 0;
+}
+
+__global__ void k_fp_update(effq_fp_state* st, double tol, int max_iter) {
+  if (st->done) return;
+  // loop head of layer_helper.py:55: while abs(a - a_prev) > 1e-5 and c < max_iter
+  double a_new = st->sums[0] / st->sums[1];
+  st->alpha_prev = st->alpha;
+  st->alpha = a_new;
+  st->iters += 1;
+  // the reference raises whenever c == max_iter, even if that last step converged (:62-64)
+  if (st->iters >= max_iter)
+    st->done = 2;
+  else if (!(fabs(st->alpha - st->alpha_prev) > tol))
+    st->done = 1;
+}
+
+__global__ __launch_bounds__(TPB) void k_presum(const float* __restrict__ a, const float* __restrict__ b,
+                                                float* __restrict__ o, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) o[i] = a[i] + b[i];
+}
+
+__global__ __launch_bounds__(TPB) void k_project_dual(const float* __restrict__ v, const float* __restrict__ wstar,
+                                                      const effq_fp_state* __restrict__ st, double d,
+                                                      float* __restrict__ G, float* __restrict__ dual,
+                                                      float dual_div, size_t n) {
+  const double alpha = st->alpha;
+  const float alpha32 = (float)alpha;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double r;
+    float b = (float)disc64((double)v[i], alpha, -1.0, 1.0, d, &r);
+    float g = alpha32 * b;
+    G[i] = g;
+    float du = (wstar[i] - g) + dual[i];        // EfficientQConv.py:111
+    if (dual_div != 1.0f) du = du / dual_div;   // "dual /= 2" or "dual /= rho_m/rho" (:131-136)
+    dual[i] = du;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_keep_best(const double* __restrict__ sqerr, double* best, int iter,
+                                                   const float* __restrict__ G, const float* __restrict__ b,
+                                                   float* __restrict__ bG, float* __restrict__ bb, size_t nw,
+                                                   size_t nb) {
+  // every thread evaluates the same predicate from the same two doubles (EfficientQConv.py:139-142)
+  const double loss = sqerr[0];
+  const double cur = best[0];
+  const bool take = (iter == 0) || (loss < cur);
+  if (!take) return;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = t0; i < nw; i += stride) bG[i] = G[i];
+  if (b != nullptr)
+    for (size_t i = t0; i < nb; i += stride) bb[i] = b[i];
+  // best[0] is rewritten by a follow-up single-thread kernel (k_commit_best) so that all blocks
+  // of this launch see the same old value
+}
+
+__global__ void k_commit_best(const double* sqerr, double* best, int iter) {
+  const double loss = sqerr[0];
+  if (iter == 0 || loss < best[0]) {
+    best[0] = loss;
+    best[1] = (double)iter;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_adam(float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v, float lr, float b1,
+                                              float b2, float eps, float bc1, float bc2, size_t n) {
+  // torch.optim.Adam (no weight decay, no amsgrad): ptqer.py:255 Adam(opt_param, lr=5e-4)
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gi = g[i];
+    float mi = m[i] + (1.0f - b1) * (gi - m[i]);          // lerp form used by torch
+    float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace effq
+
+using namespace effq;
+
+extern "C" {
+
+const char* effq_last_error(void) { return g_err; }
+int effq_version(void) { return 100; }
+
+int effq_device_count(int* count) {
+  EFFQ_CHECK_ARG(count != nullptr);
+  EFFQ_HIP(hipGetDeviceCount(count));
+  return EFFQ_OK;
+}
+
+size_t effq_reduce_ws_bytes(void) { return RED_WS_BYTES; }
+
+int effq_quant_dequant_f32(const float* x, const float* alpha_dev, float lo, float hi, int levels, float* y_out,
+                           uint8_t* idx_out, size_t n, void* stream) {
+  if (n == 0) return EFFQ_OK;  /* empty tensors are legal (and carry null pointers) */
+  EFFQ_CHECK_ARG(x && alpha_dev && levels >= 2 && hi > lo);
+  EFFQ_CHECK_ARG(idx_out == nullptr || levels <= 256);
+  const float d = (float)(((double)hi - (double)lo) / (double)(levels - 1));
+  hipLaunchKernelGGL(k_quant_dequant_f32, dim3(stream_grid((n + 3) / 4)), dim3(TPB), 0, as_stream(stream), x,
+                     alpha_dev, lo, hi, d, y_out, idx_out, n);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_quant_dequant_f64path(const float* x, const double* alpha_dev, double lo, double hi, int levels,
+                               float* y_out, float* b_out, uint8_t* idx_out, size_t n, void* stream) {
+  if (n == 0) return EFFQ_OK;  /* empty tensors are legal (and carry null pointers) */
+  EFFQ_CHECK_ARG(x && alpha_dev && levels >= 2 && hi > lo);
+  EFFQ_CHECK_ARG(idx_out == nullptr || levels <= 256);
+  const double d = (hi - lo) / (double)(levels - 1);
+  hipLaunchKernelGGL(k_quant_dequant_f64path, dim3(stream_grid((n + 3) / 4)), dim3(TPB), 0, as_stream(stream), x,
+                     alpha_dev, lo, hi, d, y_out, b_out, idx_out, n);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_abs_sum_f64(const float* x, size_t n, double* sums_out, void* ws, void* stream) {
+  EFFQ_CHECK_ARG(x && sums_out && ws && n > 0);
+  RedWs r = red_ws(ws);
+  hipLaunchKernelGGL(k_reduce<0>, dim3(stream_grid((n + 3) / 4)), dim3(TPB), 0, as_stream(stream), x, n,
+                     (const double*)nullptr, 0.0, 0.0, 0.0, (const int32_t*)nullptr, r.partials, r.ticket,
+                     sums_out);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_moments_f64(const float* x, size_t n, double* sums_out, void* ws, void* stream) {
+  EFFQ_CHECK_ARG(x && sums_out && ws && n > 0);
+  RedWs r = red_ws(ws);
+  hipLaunchKernelGGL(k_reduce<1>, dim3(stream_grid((n + 3) / 4)), dim3(TPB), 0, as_stream(stream), x, n,
+                     (const double*)nullptr, 0.0, 0.0, 0.0, (const int32_t*)nullptr, r.partials, r.ticket,
+                     sums_out);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_alpha_stats_f64(const float* x, const double* alpha_dev, double lo, double hi, int levels, size_t n,
+                         double* sums_out, const int32_t* done_flag_dev, void* ws, void* stream) {
+  EFFQ_CHECK_ARG(x && alpha_dev && sums_out && ws && n > 0 && levels >= 2 && hi > lo);
+  RedWs r = red_ws(ws);
+  const double d = (hi - lo) / (double)(levels - 1);
+  hipLaunchKernelGGL(k_reduce<2>, dim3(stream_grid((n + 3) / 4)), dim3(TPB), 0, as_stream(stream), x, n, alpha_dev,
+                     lo, hi, d, done_flag_dev, r.partials, r.ticket, sums_out);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_fp_init(effq_fp_state* state_dev, const double* abs_sums_dev, void* stream) {
+  EFFQ_CHECK_ARG(state_dev && abs_sums_dev);
+  hipLaunchKernelGGL(k_fp_init, dim3(1), dim3(1), 0, as_stream(stream), state_dev, abs_sums_dev);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_fp_update(effq_fp_state* state_dev, double tol, int max_iter, void* stream) {
+  EFFQ_CHECK_ARG(state_dev && max_iter > 0);
+  hipLaunchKernelGGL(k_fp_update, dim3(1), dim3(1), 0, as_stream(stream), state_dev, tol, max_iter);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_alpha_fixed_point(const float* x, size_t n, int levels, double lo, double hi, double tol, int max_iter,
+                           int n_iters, effq_fp_state* state_dev, void* ws, void* stream) {
+  EFFQ_CHECK_ARG(x && state_dev && ws && n > 0 && n_iters >= 0);
+  for (int i = 0; i < n_iters; ++i) {
+    int rc = effq_alpha_stats_f64(x, &state_dev->alpha, lo, hi, levels, n, state_dev->sums, &state_dev->done, ws,
+                                  stream);
+    if (rc != EFFQ_OK) return rc;
+    rc = effq_fp_update(state_dev, tol, max_iter, stream);
+    if (rc != EFFQ_OK) return rc;
+  }
+  return EFFQ_OK;
+}
+
+int effq_admm_presum(const float* wstar, const float* dual, float* v, size_t n, void* stream) {
+  EFFQ_CHECK_ARG(wstar && dual && v);
+  if (n == 0) return EFFQ_OK;
+  hipLaunchKernelGGL(k_presum, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), wstar, dual, v, n);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_admm_project_dual(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
+                           float* dual, float dual_div, size_t n, void* stream) {
+  EFFQ_CHECK_ARG(v && wstar && state_dev && G && dual && levels >= 2 && dual_div > 0.0f);
+  if (n == 0) return EFFQ_OK;
+  const double d = 2.0 / (double)(levels - 1);
+  hipLaunchKernelGGL(k_project_dual, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
+                     G, dual, dual_div, n);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_admm_keep_best(const double* sqerr_dev, double* best_dev, int iter, const float* G, const float* b,
+                        float* best_G, float* best_b, size_t nw, size_t nb, void* stream) {
+  EFFQ_CHECK_ARG(sqerr_dev && best_dev && G && best_G && iter >= 0);
+  EFFQ_CHECK_ARG((b == nullptr) == (best_b == nullptr));
+  hipLaunchKernelGGL(k_keep_best, dim3(stream_grid(nw)), dim3(TPB), 0, as_stream(stream), sqerr_dev, best_dev, iter,
+                     G, b, best_G, best_b, nw, nb);
+  EFFQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_commit_best, dim3(1), dim3(1), 0, as_stream(stream), sqerr_dev, best_dev, iter);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_adam_step(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, int t,
+                   size_t n, void* stream) {
+  EFFQ_CHECK_ARG(p && g && m && v && t >= 1);
+  if (n == 0) return EFFQ_OK;
+  const float bc1 = 1.0f - powf(b1, (float)t), bc2 = 1.0f - powf(b2, (float)t);
+  hipLaunchKernelGGL(k_adam, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), p, g, m, v, lr, b1, b2, eps, bc1,
+                     bc2, n);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,338 @@
+// Proximal step of the ADMM: system matrix, fp64 SPD inverse (cached per rho by the caller) and the
+// per-iteration  What = B * A^-1  product on the f32 matrix cores.
+// Reference: solver.py:316-325 (getAB), :327-345 (solve; torch.linalg.solve = LU, every iteration).
+//
+// A = A0 + rho*I' + eta*I is symmetric positive definite (PSD Gram + eta*I, eta>0), and it changes
+// only when rho does (5 values per layer), so the inverse is formed once per rho in fp64 by a
+// blocked in-place Gauss-Jordan sweep (no pivoting needed for SPD) whose bulk is a rank-64 fp64
+// MFMA update (v_mfma_f64_16x16x4_f64), then rounded once to fp32.
+#include "common.h"
+
+namespace effq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NBK = 64;        // Gauss-Jordan block size
+constexpr int LDA_S = 66;      // LDS leading dims (doubles): conflict-free ds_read_b64 operand fetches
+constexpr int LDB_S = 80;
+
+// A64 (npad x npad, row-major) = A0 + diag, identity on the padding
+__global__ __launch_bounds__(256) void k_build_a64(const float* __restrict__ A0, int n, int npad, int has_bias,
+                                                   double rho, double eta, double* __restrict__ A64) {
+  const size_t tot = (size_t)npad * npad;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) {
+    const int i = (int)(e / npad), j = (int)(e % npad);
+    double v = 0.0;
+    if (i < n && j < n) {
+      v = (double)A0[(size_t)i * n + j];
+      if (i == j) v += eta + ((has_bias && i == n - 1) ? 0.0 : rho);
+    } else if (i == j) {
+      v = 1.0;
+    }
+    A64[e] = v;
+  }
+}
+
+// Step 1: Dinv = inv(A[kb:kb+64, kb:kb+64]) by unblocked in-place Gauss-Jordan in LDS.
+__global__ __launch_bounds__(256) void k_gj_diag(const double* __restrict__ A, int npad, int kb,
+                                                 double* __restrict__ Dinv) {
+  __shared__ double Ds[NBK][NBK + 1];
+  const int tid = threadIdx.x;
+  const int i = tid >> 2, j0 = (tid & 3) * 16;
+  for (int j = 0; j < 16; ++j) Ds[i][j0 + j] = A[(size_t)(kb + i) * npad + kb + j0 + j];
+  __syncthreads();
+  for (int p = 0; p < NBK; ++p) {
+    const double piv = 1.0 / Ds[p][p];
+    const double f = Ds[i][p];
+    double rowp[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) rowp[j] = Ds[p][j0 + j] * piv;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int jj = j0 + j;
+      double v;
+      if (i == p)
+        v = (jj == p) ? piv : rowp[j];
+      else
+        v = (jj == p) ? (-f * piv) : (Ds[i][jj] - f * rowp[j]);
+      Ds[i][jj] = v;
+    }
+    __syncthreads();
+  }
+  for (int j = 0; j < 16; ++j) Dinv[i * NBK + j0 + j] = Ds[i][j0 + j];
+}
+
+// 64x64x64 fp64 tile product on the matrix cores: acc += As(64x64) * Bs(64x64), one 32x32 quadrant per wave.
+__device__ __forceinline__ void tile_mma64(const double* As, const double* Bs, f64x4 (&acc)[2][2]) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll 4
+  for (int ks = 0; ks < NBK / 4; ++ks) {
+    double a[2], b[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a[mi] = As[(wr * 32 + mi * 16 + lr) * LDA_S + ks * 4 + lk];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) b[ni] = Bs[(ks * 4 + lk) * LDB_S + wc * 32 + ni * 16 + lr];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void load_tile(double* dst, int ld, const double* src, size_t src_ld) {
+  // 64x64 doubles, 256 threads, 16 per thread, coalesced along rows
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NBK * NBK; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    dst[r * ld + c] = src[(size_t)r * src_ld + c];
+  }
+}
+
+// mode 0 (row panel):   R[:, jb]   =  Dinv * A[kb, jb]                      grid.x = npad/64 (j blocks)
+// mode 1 (trailing):    A[ib, jb] -=  A[ib, kb] * R[:, jb]     (ib,jb != kb) grid = (npad/64, npad/64)
+// mode 2 (finalize):    A[ib, kb]  = -A[ib, kb] * Dinv (ib != kb);  A[kb, jb] = R[:, jb];  A[kb,kb] = Dinv
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gj_step(double* __restrict__ A, int npad, int kb,
+                                                 const double* __restrict__ Dinv, double* __restrict__ R) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* As = sm;
+  double* Bs = sm + NBK * LDA_S;
+  const int kblk = kb / NBK;
+  const int jb = blockIdx.x, ib = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0;
+
+  if (MODE == 0) {
+    if (jb == kblk) return;
+    load_tile(As, LDA_S, Dinv, NBK);
+    load_tile(Bs, LDB_S, A + (size_t)kb * npad + (size_t)jb * NBK, npad);
+  } else if (MODE == 1) {
+    if (jb == kblk || ib == kblk) return;
+    load_tile(As, LDA_S, A + (size_t)ib * NBK * npad + kb, npad);
+    load_tile(Bs, LDB_S, R + (size_t)jb * NBK, npad);
+  } else {
+    // blockIdx.x enumerates both the column-panel tiles (ib = x) and the row-panel tiles
+    if (jb == kblk) {
+      // A[kb,kb] = Dinv
+      for (int e = threadIdx.x; e < NBK * NBK; e += 256)
+        A[(size_t)(kb + (e >> 6)) * npad + kb + (e & 63)] = Dinv[e];
+      return;
+    }
+    // row panel copy: A[kb, jb] = R[:, jb]
+    for (int e = threadIdx.x; e < NBK * NBK; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      A[(size_t)(kb + r) * npad + (size_t)jb * NBK + c] = R[(size_t)r * npad + (size_t)jb * NBK + c];
+    }
+    // column panel: tile ib = jb
+    load_tile(As, LDA_S, A + (size_t)jb * NBK * npad + kb, npad);
+    load_tile(Bs, LDB_S, Dinv, NBK);
+  }
+  __syncthreads();
+  tile_mma64(As, Bs, acc);
+
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * 32 + mi * 16 + lk + 4 * r;
+        const int col = wc * 32 + ni * 16 + lr;
+        if (MODE == 0) {
+          R[(size_t)row * npad + (size_t)jb * NBK + col] = acc[mi][ni][r];
+        } else if (MODE == 1) {
+          double* d = A + (size_t)(ib * NBK + row) * npad + (size_t)jb * NBK + col;
+          *d = *d - acc[mi][ni][r];
+        } else {
+          A[(size_t)(jb * NBK + row) * npad + kb + col] = -acc[mi][ni][r];
+        }
+      }
+}
+
+__global__ __launch_bounds__(256) void k_a64_to_f32(const double* __restrict__ A64, int n, int npad,
+                                                    float* __restrict__ Ainv) {
+  const size_t tot = (size_t)n * n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) {
+    const int i = (int)(e / n), j = (int)(e % n);
+    // symmetrise: the exact inverse is symmetric; average the two computed halves
+    Ainv[e] = (float)(0.5 * (A64[(size_t)i * npad + j] + A64[(size_t)j * npad + i]));
+  }
+}
+
+// Bm[c2][ldb] = B0 + eta*[W0|b0] + rho*[G-dual|0]     (solver.py:316-322, fp32, reference op order)
+__global__ __launch_bounds__(256) void k_build_b(const float* __restrict__ B0, const float* __restrict__ W0,
+                                                 const float* __restrict__ b0, const float* __restrict__ G,
+                                                 const float* __restrict__ dual, int c2, int n, int has_bias,
+                                                 float rho, float eta, float* __restrict__ Bm, int ldb, int c2p) {
+  const size_t tot = (size_t)c2p * ldb;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int nw = n - has_bias;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) {
+    const int r = (int)(e / ldb), k = (int)(e % ldb);
+    float v = 0.0f;
+    if (r < c2 && k < n) {
+      if (k < nw) {
+        const size_t wi = (size_t)r * nw + k;
+        v = B0[(size_t)r * n + k] + eta * W0[wi];
+        v = v + rho * (G[wi] - dual[wi]);
+      } else {
+        v = B0[(size_t)r * n + k] + eta * b0[r];
+      }
+    }
+    Bm[e] = v;
+  }
+}
+
+// What = Bm * Ainv (Ainv symmetric n x n).  One wave per 32x32 output tile, K = n, operands read
+// straight from L2 (Bm as 16-byte fragments, Ainv rows coalesced across lanes).
+__global__ __launch_bounds__(256) void k_prox_gemm(const float* __restrict__ Bm, int ldb, const float* __restrict__ Ainv,
+                                                   int n, int c2, int has_bias, float* __restrict__ wstar,
+                                                   float* __restrict__ bstar, int ntile_n) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wtile = blockIdx.x * 4 + wid;
+  const int tn = wtile % ntile_n, tm = wtile / ntile_n;
+  if (tm * 32 >= ((c2 + 31) / 32) * 32) return;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const int col = tn * 32 + li;
+  const bool colok = col < n;
+  const float* brow = Bm + (size_t)(tm * 32 + li) * ldb + 4 * lh;
+  const int k8 = ldb / 8;  // ldb is a multiple of 8; rows k >= n of Ainv are never dereferenced
+  for (int kk = 0; kk < k8; ++kk) {
+    const float4 a = *reinterpret_cast<const float4*>(brow + kk * 8);
+    const int k0 = kk * 8 + 4 * lh;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (colok) {
+      if (k0 + 0 < n) b0 = Ainv[(size_t)(k0 + 0) * n + col];
+      if (k0 + 1 < n) b1 = Ainv[(size_t)(k0 + 1) * n + col];
+      if (k0 + 2 < n) b2 = Ainv[(size_t)(k0 + 2) * n + col];
+      if (k0 + 3 < n) b3 = Ainv[(size_t)(k0 + 3) * n + col];
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+  }
+  const int nw = n - has_bias;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (row < c2 && colok) {
+      if (col < nw)
+        wstar[(size_t)row * nw + col] = acc[r];
+      else
+        bstar[row] = acc[r];
+    }
+  }
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace effq
+
+using namespace effq;
+
+extern "C" {
+
+size_t effq_spd_inverse_ws_bytes(int n) {
+  if (n <= 0) return 0;
+  const size_t npad = (size_t)round_up(n, NBK);
+  return npad * npad * sizeof(double) + (size_t)NBK * npad * sizeof(double) + NBK * NBK * sizeof(double) + 256;
+}
+
+int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double eta, float* Ainv, void* ws,
+                     size_t ws_bytes, void* stream) {
+  EFFQ_CHECK_ARG(A0 && Ainv && ws && n > 0);
+  EFFQ_CHECK_ARG(eta > 0.0 && rho >= 0.0);
+  if (ws_bytes < effq_spd_inverse_ws_bytes(n)) {
+    set_error("spd_inverse: workspace %zu < required %zu", ws_bytes, effq_spd_inverse_ws_bytes(n));
+    return EFFQ_ERR_WORKSPACE;
+  }
+  const int npad = round_up(n, NBK);
+  const int nblk = npad / NBK;
+  double* A64 = reinterpret_cast<double*>(ws);
+  double* R = A64 + (size_t)npad * npad;
+  double* Dinv = R + (size_t)NBK * npad;
+  hipStream_t st = as_stream(stream);
+  {
+    size_t nb = ((size_t)npad * npad + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_build_a64, dim3((unsigned)nb), dim3(256), 0, st, A0, n, npad, has_bias, rho, eta, A64);
+    EFFQ_LAUNCH_CHECK();
+  }
+  const size_t lds = (size_t)(NBK * LDA_S + NBK * LDB_S) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_step<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_step<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  for (int k = 0; k < nblk; ++k) {
+    const int kb = k * NBK;
+    hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(256), 0, st, A64, npad, kb, Dinv);
+    if (nblk > 1) {
+      hipLaunchKernelGGL(k_gj_step<0>, dim3(nblk, 1), dim3(256), lds, st, A64, npad, kb, Dinv, R);
+      hipLaunchKernelGGL(k_gj_step<1>, dim3(nblk, nblk), dim3(256), lds, st, A64, npad, kb, Dinv, R);
+    }
+    hipLaunchKernelGGL(k_gj_step<2>, dim3(nblk, 1), dim3(256), lds, st, A64, npad, kb, Dinv, R);
+    EFFQ_LAUNCH_CHECK();
+  }
+  {
+    size_t nb = ((size_t)n * n + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_a64_to_f32, dim3((unsigned)nb), dim3(256), 0, st, A64, n, npad, Ainv);
+    EFFQ_LAUNCH_CHECK();
+  }
+  return EFFQ_OK;
+}
+
+size_t effq_prox_ws_bytes(int c2, int n) {
+  if (c2 <= 0 || n <= 0) return 0;
+  return (size_t)round_up(c2, 32) * round_up(n, 8) * sizeof(float) + 256;
+}
+
+int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
+                    const float* dual, int c2, int n, int has_bias, double rho, double eta, float* wstar, float* bstar,
+                    void* ws, size_t ws_bytes, void* stream) {
+  EFFQ_CHECK_ARG(B0 && Ainv && W0 && G && dual && wstar && ws && c2 > 0 && n > 0);
+  EFFQ_CHECK_ARG(!has_bias || (b0 != nullptr && bstar != nullptr));
+  if (ws_bytes < effq_prox_ws_bytes(c2, n)) {
+    set_error("prox_solve: workspace %zu < required %zu", ws_bytes, effq_prox_ws_bytes(c2, n));
+    return EFFQ_ERR_WORKSPACE;
+  }
+  const int c2p = round_up(c2, 32), ldb = round_up(n, 8);
+  float* Bm = reinterpret_cast<float*>(ws);
+  hipStream_t st = as_stream(stream);
+  {
+    size_t nb = ((size_t)c2p * ldb + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_build_b, dim3((unsigned)nb), dim3(256), 0, st, B0, W0, b0, G, dual, c2, n, has_bias ? 1 : 0,
+                       (float)rho, (float)eta, Bm, ldb, c2p);
+    EFFQ_LAUNCH_CHECK();
+  }
+  const int ntile_n = (n + 31) / 32, ntile_m = c2p / 32;
+  const int nwt = ntile_n * ntile_m;
+  hipLaunchKernelGGL(k_prox_gemm, dim3((nwt + 3) / 4), dim3(256), 0, st, Bm, ldb, Ainv, n, c2, has_bias ? 1 : 0, wstar,
+                     bstar, ntile_n);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+"""Tensor-level front end of the C-ABI library: torch tensors supply device memory and
+the HIP stream; every computation is a call into ``libeffq_hip.so``.
+
+No CPU fallback exists here on purpose: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Geom, check
+
+ADMM_TOL = 1e-5   # layer_helper.py:55
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def to_ndhwc(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,D,H,W) logical -> contiguous (N,D,H,W,C) storage (no copy if already channels_last_3d)."""
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def from_ndhwc(t: torch.Tensor) -> torch.Tensor:
+    """contiguous (N,D,H,W,C) -> logical (N,C,D,H,W) view (channels_last_3d strides)."""
+    return t.permute(0, 4, 1, 2, 3)
+
+
+def _triple(v):
+    return (v, v, v) if isinstance(v, int) else tuple(int(i) for i in v)
+
+
+def make_geom(x_shape_ncdhw, c2: int, ksize, stride, padding) -> Geom:
+    n, c1, d, h, w = (int(i) for i in x_shape_ncdhw)
+    k, s, p = _triple(ksize), _triple(stride), _triple(padding)
+    return Geom(n, c1, int(c2), d, h, w, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
+
+
+def _check_shapes(geom: Geom, x, w=None, bias=None, y=None, att=None):
+    """Host-side guard: buffer sizes must match what the kernels index (an out-of-bounds access
+    on the device can take the whole node down)."""
+    od, oh, ow = geom.out_dims()
+    if min(od, oh, ow) <= 0:
+        raise _lib.EffqError(f"empty conv output for geometry {[getattr(geom, f[0]) for f in geom._fields_]}")
+    want = {"x": (x, geom.N * geom.D * geom.H * geom.W * geom.C1),
+            "weight": (w, geom.C2 * geom.C1 * geom.KD * geom.KH * geom.KW),
+            "bias": (bias, geom.C2),
+            "y": (y, geom.N * od * oh * ow * geom.C2),
+            "att": (att, geom.N * od * oh * ow)}
+    for name, (t, n) in want.items():
+        if t is not None and t.numel() != n:
+            raise _lib.EffqError(f"{name} has {t.numel()} elements, geometry needs {n}")
+
+
+class HipOps:
+    """Per-device handle: stream + library-owned workspaces (grown on demand, never shrunk)."""
+
+    def __init__(self, device: torch.device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.EffqError(f"efficientq_amd runs on a HIP device only, got {device} (no CPU fallback)")
+        self.lib = _lib.load()
+        self.device = device
+        self._red_ws = torch.zeros(self.lib.effq_reduce_ws_bytes(), dtype=torch.uint8, device=device)
+        self._ws = {}
+
+    # -- plumbing ---------------------------------------------------------------------------
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        cur = self._ws.get(key)
+        if cur is None or cur.numel() < nbytes:
+            cur = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._ws[key] = cur
+        return cur
+
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        if t.device != self.device and not (t.device.type == "cuda" and self.device.index in (None, t.device.index)):
+            raise _lib.EffqError(f"tensor on {t.device}, ops on {self.device}")
+        if t.dtype != torch.float32:
+            raise _lib.EffqError(f"expected float32, got {t.dtype}")
+        return t if t.is_contiguous() else t.contiguous()
+
+    # -- a1/a3 --------------------------------------------------------------------------------
+    def quant_dequant_f32(self, x: torch.Tensor, alpha: torch.Tensor, levels: int, lo: float, hi: float,
+                          want_idx: bool = False):
+        """PTQConv._quantize_act / discretize in fp32 (PTQConv.py:114-116).  alpha: 0-dim device tensor."""
+        x = self._f32(x)
+        a = self._f32(alpha.reshape(1))
+        y = torch.empty_like(x)
+        idx = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_idx else None
+        check(self.lib.effq_quant_dequant_f32(_ptr(x), _ptr(a), lo, hi, levels, _ptr(y), _ptr(idx), x.numel(),
+                                              self.stream), "effq_quant_dequant_f32")
+        return (y, idx) if want_idx else y
+
+    def quant_dequant_f64path(self, x: torch.Tensor, state: torch.Tensor, levels: int, lo: float, hi: float,
+                              want_b: bool = False, want_idx: bool = False):
+        """a*b of project_by_iter (layer_helper.py:66, EfficientQConv.py:70); alpha = state[0] (device double)."""
+        x = self._f32(x)
+        y = torch.empty_like(x)
+        b = torch.empty_like(x) if want_b else None
+        idx = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_idx else None
+        check(self.lib.effq_quant_dequant_f64path(_ptr(x), _ptr(state), lo, hi, levels, _ptr(y), _ptr(b), _ptr(idx),
+                                                  x.numel(), self.stream), "effq_quant_dequant_f64path")
+        return y, b, idx
+
+    # -- a2 -----------------------------------------------------------------------------------
+    def abs_sum(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._f32(x)
+        out = torch.empty(2, dtype=torch.float64, device=x.device)
+        check(self.lib.effq_abs_sum_f64(_ptr(x), x.numel(), _ptr(out), _ptr(self._red_ws), self.stream),
+              "effq_abs_sum_f64")
+        return out
+
+    def moments(self, x: torch.Tensor) -> torch.Tensor:
+        """[sum, sum of squares, count] in fp64 on the device."""
+        x = self._f32(x)
+        out = torch.empty(3, dtype=torch.float64, device=x.device)
+        check(self.lib.effq_moments_f64(_ptr(x), x.numel(), _ptr(out), _ptr(self._red_ws), self.stream),
+              "effq_moments_f64")
+        return out
+
+    def new_fp_state(self) -> torch.Tensor:
+        # effq_fp_state viewed as 5 doubles: alpha, alpha_prev, sums[2], {iters,done}
+        return torch.zeros(5, dtype=torch.float64, device=self.device)
+
+    @staticmethod
+    def read_fp_state(state: torch.Tensor):
+        host = state.cpu()
+        iters, done = host[4:5].view(torch.int32).tolist()
+        return float(host[0]), int(iters), int(done)
+
+    def fit_scale(self, x: torch.Tensor, levels: int, lo: float, hi: float, reducer=None,
+                  guess_iters: int = 16, state: Optional[torch.Tensor] = None):
+        """project_by_iter on the device (layer_helper.py:40-70).
+
+        ``reducer`` (callable on a device fp64 tensor, in place) sums statistics over data-parallel
+        ranks; with it the statistics of every iteration are all-reduced before the update.
+        Returns (alpha: float, iters: int, state tensor).  Raises RuntimeWarning like the
+        reference when the cap 100*L is hit.
+        """
+        x = self._f32(x)
+        n = x.numel()
+        st = state if state is not None else self.new_fp_state()
+        cap = 100 * levels
+        s0 = self.abs_sum(x)
+        if reducer is not None:
+            reducer(s0)
+        check(self.lib.effq_fp_init(_ptr(st), _ptr(s0), self.stream), "effq_fp_init")
+        batch = max(4, int(guess_iters))
+        while True:
+            if reducer is None:
+                check(self.lib.effq_alpha_fixed_point(_ptr(x), n, levels, lo, hi, ADMM_TOL, cap, batch, _ptr(st),
+                                                      _ptr(self._red_ws), self.stream), "effq_alpha_fixed_point")
+            else:
+                sums = st[2:4]
+                done = st[4:5]
+                for _ in range(batch):
+                    check(self.lib.effq_alpha_stats_f64(_ptr(x), _ptr(st), lo, hi, levels, n, _ptr(sums),
+                                                        C.c_void_p(done.data_ptr() + 4), _ptr(self._red_ws),
+                                                        self.stream), "effq_alpha_stats_f64")
+                    reducer(sums)
+                    check(self.lib.effq_fp_update(_ptr(st), ADMM_TOL, cap, self.stream), "effq_fp_update")
+            alpha, iters, done = self.read_fp_state(st)   # one host sync per batch
+            if done == 1:
+                return alpha, iters, st
+            if done == 2:
+                raise RuntimeWarning(f"Exceed maximum iteration ({cap}) for alpha optimization")
+            batch = min(max(8, iters // 2), 256)
+
+    # -- a5/a6 --------------------------------------------------------------------------------
+    def gram(self, x_ndhwc: torch.Tensor, att: Optional[torch.Tensor], y_ndhwc: torch.Tensor, geom: Geom,
+             has_bias: bool, A0: Optional[torch.Tensor] = None, B0: Optional[torch.Tensor] = None):
+        """A0 (n x n), B0 (c2 x n) of solver.py:282-314, reference row order.  Accumulates when A0/B0 given."""
+        x = self._f32(x_ndhwc)
+        y = self._f32(y_ndhwc)
+        a = self._f32(att) if att is not None else None
+        _check_shapes(geom, x, y=y, att=a)
+        n = geom.C1 * geom.KD * geom.KH * geom.KW + int(has_bias)
+        acc = int(A0 is not None)
+        if A0 is not None and (tuple(A0.shape) != (n, n) or tuple(B0.shape) != (geom.C2, n)):
+            raise _lib.EffqError("gram: A0/B0 shapes do not match the geometry")
+        if A0 is None:
+            A0 = torch.empty(n, n, dtype=torch.float32, device=self.device)
+            B0 = torch.empty(geom.C2, n, dtype=torch.float32, device=self.device)
+        need = self.lib.effq_gram_ws_bytes(C.byref(geom), int(has_bias))
+        ws = self._workspace("gram", need)
+        check(self.lib.effq_gram_accum(_ptr(x), _ptr(a), _ptr(y), C.byref(geom), int(has_bias), _ptr(A0), _ptr(B0),
+                                       acc, _ptr(ws), ws.numel(), self.stream), "effq_gram_accum")
+        return A0, B0
+
+    # -- a7 -----------------------------------------------------------------------------------
+    def spd_inverse(self, A0: torch.Tensor, has_bias: bool, rho: float, eta: float,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        n = A0.shape[0]
+        A0 = self._f32(A0)
+        if out is None:
+            out = torch.empty(n, n, dtype=torch.float32, device=self.device)
+        ws = self._workspace("inv", self.lib.effq_spd_inverse_ws_bytes(n))
+        check(self.lib.effq_spd_inverse(_ptr(A0), n, int(has_bias), rho, eta, _ptr(out), _ptr(ws), ws.numel(),
+                                        self.stream), "effq_spd_inverse")
+        return out
+
+    def prox_solve(self, B0, Ainv, W0, b0, G, dual, rho: float, eta: float, wstar, bstar):
+        c2, n = B0.shape
+        ws = self._workspace("prox", self.lib.effq_prox_ws_bytes(c2, n))
+        check(self.lib.effq_prox_solve(_ptr(B0), _ptr(Ainv), _ptr(W0), _ptr(b0), _ptr(G), _ptr(dual), c2, n,
+                                       int(b0 is not None), rho, eta, _ptr(wstar), _ptr(bstar), _ptr(ws),
+                                       ws.numel(), self.stream), "effq_prox_solve")
+
+    # -- a4 elementwise -------------------------------------------------------------------------
+    def admm_presum(self, wstar, dual, v):
+        check(self.lib.effq_admm_presum(_ptr(wstar), _ptr(dual), _ptr(v), wstar.numel(), self.stream),
+              "effq_admm_presum")
+
+    def admm_project_dual(self, v, wstar, state, levels: int, G, dual, dual_div: float):
+        check(self.lib.effq_admm_project_dual(_ptr(v), _ptr(wstar), _ptr(state), levels, _ptr(G), _ptr(dual),
+                                              float(dual_div), v.numel(), self.stream), "effq_admm_project_dual")
+
+    def admm_keep_best(self, sqerr, best, it: int, G, b, best_G, best_b):
+        check(self.lib.effq_admm_keep_best(_ptr(sqerr), _ptr(best), it, _ptr(G), _ptr(b), _ptr(best_G), _ptr(best_b),
+                                           G.numel(), 0 if b is None else b.numel(), self.stream),
+              "effq_admm_keep_best")
+
+    # -- the conv ---------------------------------------------------------------------------------
+    def conv_step(self, x_ndhwc: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], geom: Geom,
+                  y_ndhwc: Optional[torch.Tensor] = None, att: Optional[torch.Tensor] = None,
+                  act_alpha: Optional[torch.Tensor] = None, act_levels: int = 0, want_out: bool = False,
+                  sqerr: Optional[torch.Tensor] = None):
+        """conv3d_quant_calib_step.  Returns (out NDHWC or None, sqerr device fp64[2] or None)."""
+        x = self._f32(x_ndhwc)
+        w = self._f32(weight)
+        b = self._f32(bias) if bias is not None else None
+        y = self._f32(y_ndhwc) if y_ndhwc is not None else None
+        a = self._f32(att) if att is not None else None
+        _check_shapes(geom, x, w, b, y, a)
+        od, oh, ow = geom.out_dims()
+        out = torch.empty(geom.N, od, oh, ow, geom.C2, dtype=torch.float32, device=self.device) if want_out else None
+        if y is not None and sqerr is None:
+            sqerr = torch.empty(2, dtype=torch.float64, device=self.device)
+        al = self._f32(act_alpha.reshape(1)) if act_alpha is not None else None
+        ws = self._workspace("conv", self.lib.effq_conv_ws_bytes(C.byref(geom)))
+        check(self.lib.conv3d_quant_calib_step(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(a), C.byref(geom), _ptr(al),
+                                               int(act_levels), _ptr(sqerr), _ptr(out), _ptr(ws), ws.numel(),
+                                               self.stream), "conv3d_quant_calib_step")
+        return out, sqerr
+
+
+_OPS = {}
+
+
+def get_ops(device) -> HipOps:
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = str(device)
+    if key not in _OPS:
+        _OPS[key] = HipOps(device)
+    return _OPS[key]

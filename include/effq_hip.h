@@ -1,0 +1,160 @@
+/*
+ * effq_hip.h -- C ABI of the MI355X (gfx950) hot path of EfficientQ's layer-wise
+ * PTQ calibration.  This is the drop-in boundary: plain pointers and sizes, no
+ * torch types, every call returns an int status (EFFQ_OK == 0; no exceptions
+ * cross the ABI), every buffer is a caller-owned DEVICE pointer unless the
+ * parameter says "host", every call takes the HIP stream to enqueue on
+ * (a hipStream_t passed as void*; NULL = default stream) and never
+ * synchronises unless documented.  The reference has no FFI of its own (it is
+ * pure Python); each entry point cites the reference code it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Layouts
+ *   activations / targets : NDHWC fp32 (torch channels_last_3d), x[n][d][h][w][c]
+ *   attention mask        : [n][D'][H'][W'] fp32 (one weight per output voxel)
+ *   weights               : reference layout [c2][c1][kd][kh][kw] fp32
+ *   Gram system           : A0 [n x n], B0 [c2 x n] row-major fp32, n = c1*k^3 (+1 bias),
+ *                           row order (c1,kd,kh,kw)+bias exactly as solver.py:104-108,256
+ */
+#ifndef EFFQ_HIP_H
+#define EFFQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  EFFQ_OK = 0,
+  EFFQ_ERR_ARG = 1,        /* bad argument (null pointer, bad shape, unsupported geometry) */
+  EFFQ_ERR_HIP = 2,        /* a HIP runtime call failed; see effq_last_error() */
+  EFFQ_ERR_WORKSPACE = 3,  /* workspace too small; query the *_ws_bytes function */
+  EFFQ_ERR_NO_DEVICE = 4,
+  EFFQ_ERR_NOT_CONVERGED = 5
+};
+
+/* Conv geometry.  Dilation and groups are 1 (the reference's solver ignores
+ * them, solver.py:86-111, and both shipped configs use 1). */
+typedef struct effq_geom {
+  int32_t N, C1, C2;
+  int32_t D, H, W;          /* input spatial size  */
+  int32_t KD, KH, KW;       /* 1 or 3 per axis      */
+  int32_t SD, SH, SW;       /* stride               */
+  int32_t PD, PH, PW;       /* symmetric zero pad   */
+} effq_geom;
+
+const char* effq_last_error(void);
+int effq_version(void);
+/* Number of HIP devices visible; does not initialise a context. */
+int effq_device_count(int* count);
+
+/* ---- a1/a3: discretize + PTQConv._quantize_act -------------------------------
+ * layer_helper.py:25-37, PTQConv.py:114-116.
+ * fp32 path: y = (rint((clamp(x/alpha,lo,hi)-lo)/d)*d+lo)*alpha with d=f32((hi-lo)/(L-1)),
+ * IEEE divisions, round-half-even, no FMA contraction.  alpha is read from DEVICE
+ * memory (one float).  idx_out (uint8 level ids) and y_out may each be NULL. */
+int effq_quant_dequant_f32(const float* x, const float* alpha_dev, float lo, float hi, int levels,
+                           float* y_out, uint8_t* idx_out, size_t n, void* stream);
+
+/* fp64 path used during calibration (project_by_iter's final discretize,
+ * layer_helper.py:50-66, then "a * b", EfficientQConv.py:68-70):
+ * b = f32(discretize(f64(x)/alpha)), y = f32(alpha)*b.  alpha is a DEVICE double. */
+int effq_quant_dequant_f64path(const float* x, const double* alpha_dev, double lo, double hi, int levels,
+                               float* y_out, float* b_out, uint8_t* idx_out, size_t n, void* stream);
+
+/* ---- a2: project_by_iter pieces (layer_helper.py:40-70) -----------------------
+ * Workspace for all reductions below: effq_reduce_ws_bytes() bytes, zero-initialised
+ * once by the caller (hipMemset) and then owned by this library between calls. */
+size_t effq_reduce_ws_bytes(void);
+
+/* sums_out[0] = sum |x_i| (fp64), sums_out[1] = n (2 doubles).  (a = var.abs().mean(), layer_helper.py:51) */
+int effq_abs_sum_f64(const float* x, size_t n, double* sums_out, void* ws, void* stream);
+
+/* sums_out[0] = sum x, [1] = sum x^2 (fp64), [2] = n.  (Tensor.std(), EfficientQConv.py:46,48) */
+int effq_moments_f64(const float* x, size_t n, double* sums_out, void* ws, void* stream);
+
+/* One fixed-point statistics pass: b = discretize(f64(x)/alpha); sums_out[0] = sum b*x,
+ * sums_out[1] = sum b*b (layer_helper.py:57-59).  alpha is a DEVICE double.  If
+ * done_flag_dev is non-NULL and *done_flag_dev != 0 the pass is skipped. */
+int effq_alpha_stats_f64(const float* x, const double* alpha_dev, double lo, double hi, int levels,
+                         size_t n, double* sums_out, const int32_t* done_flag_dev, void* ws, void* stream);
+
+/* Fixed-point state on the device: {alpha, alpha_prev, sums[2], iters, done}. */
+typedef struct effq_fp_state {
+  double alpha;
+  double alpha_prev;
+  double sums[2];
+  int32_t iters;
+  int32_t done;      /* 1 converged, 2 hit max_iter (the reference raises, layer_helper.py:62-64) */
+} effq_fp_state;
+
+/* state.alpha = sums[0]/sums[1] (abs-mean start), alpha_prev=-999, iters=0, done=0. */
+int effq_fp_init(effq_fp_state* state_dev, const double* abs_sums_dev, void* stream);
+/* alpha_prev=alpha; alpha=sums[0]/sums[1]; ++iters; done when |alpha-alpha_prev|<=tol or iters==max_iter.
+ * Reads state->sums (so an all-reduce of state->sums may run between stats and update). */
+int effq_fp_update(effq_fp_state* state_dev, double tol, int max_iter, void* stream);
+
+/* Whole fixed point on the stream without host round trips: runs stats+update
+ * `n_iters` times (each a no-op once done).  The caller checks state.done afterwards. */
+int effq_alpha_fixed_point(const float* x, size_t n, int levels, double lo, double hi, double tol,
+                           int max_iter, int n_iters, effq_fp_state* state_dev, void* ws, void* stream);
+
+/* ---- a5/a6: im2col + getA0B0 (solver.py:86-111, 282-314), never materialising x_col ----
+ * A0 = 2*sum_v att_v xhat_v xhat_v^T, B0 = 2*sum_v att_v y_v xhat_v^T; xhat has a trailing 1
+ * when has_bias.  att may be NULL (all ones).  accumulate!=0 adds into A0/B0 (sharded volumes).
+ * ws: effq_gram_ws_bytes(geom) bytes. */
+size_t effq_gram_ws_bytes(const effq_geom* g, int has_bias);
+int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc, const effq_geom* g,
+                    int has_bias, float* A0, float* B0, int accumulate, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* ---- a7: getAB + solve (solver.py:316-345) --------------------------------------
+ * Ainv = (A0 + rho*I' + eta*I)^-1 in fp64 (I' has 0 on the bias diagonal), stored fp32 [n x n].
+ * The reference refactorises per iteration; A only changes with rho (5 values per layer). */
+size_t effq_spd_inverse_ws_bytes(int n);
+int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double eta, float* Ainv,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* What = (B0 + eta*[W0|b0] + rho*[G-dual|0]) * Ainv ; splits into wstar [c2 x (n-1|n)] and bstar [c2].
+ * W0, G, dual, wstar in reference weight layout (contiguous c2 x c1k).  b0/bstar NULL when !has_bias.
+ * rho/eta are host doubles.  ws: effq_prox_ws_bytes(c2,n). */
+size_t effq_prox_ws_bytes(int c2, int n);
+int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
+                    const float* dual, int c2, int n, int has_bias, double rho, double eta, float* wstar,
+                    float* bstar, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a4: ADMM elementwise steps (EfficientQConv.py:108-111,129-137,139-142) ----
+ * v = wstar + dual                                  (input of the weight projection) */
+int effq_admm_presum(const float* wstar, const float* dual, float* v, size_t n, void* stream);
+/* G = f32(alpha)*b with b=f32(discretize(f64(v)/alpha,-1,1)); dual = (wstar - G + dual) / dual_div.
+ * dual_div is 1, or 2 / (rho_max/rho) on the rho-schedule iterations (i % 50 == 0).  alpha from state_dev. */
+int effq_admm_project_dual(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels,
+                           float* G, float* dual, float dual_div, size_t n, void* stream);
+/* Best-iterate bookkeeping on the device: if (iter==0 || loss<best_loss) copy G,b into best_G,best_b.
+ * loss_dev = {sum sq err (double)}; best_dev = {best loss (double), best iter (as double)}. */
+int effq_admm_keep_best(const double* sqerr_dev, double* best_dev, int iter, const float* G, const float* b,
+                        float* best_G, float* best_b, size_t nw, size_t nb, void* stream);
+
+/* ---- the entry point north_star names ------------------------------------------------
+ * One ADMM iteration's device work (EfficientQConv.py:118-122,161-165; PTQConv.py:154-167):
+ * out = conv3d(xq, G, bias) in fp32 on the matrix cores (f32 MFMA, exact fp32 fma chains),
+ * fused with sqerr_out[0] = sum (out-y)^2 and sqerr_out[1] = sum att*(out-y)^2 (fp64 scalars).
+ * y_fp may be NULL (plain forward), out may be NULL (loss only), att may be NULL (sqerr[1]=sqerr[0]).
+ * If act_alpha_dev != NULL the fp32 quant-dequant of PTQConv._quantize_act (levels act_levels,
+ * range [0,1]) is applied to x while staging it (quantised forward, PTQConv.py:163-167).
+ * ws: effq_conv_ws_bytes(geom). */
+size_t effq_conv_ws_bytes(const effq_geom* g);
+int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* bias, const float* y_fp,
+                            const float* att, const effq_geom* g, const float* act_alpha_dev, int act_levels,
+                            double* sqerr_out, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- f3 (next row): Adam step for tune_activation_range (ptqer.py:238-272) ---- */
+int effq_adam_step(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
+                   int t, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFFQ_HIP_H */

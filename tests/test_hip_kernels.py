@@ -1,0 +1,269 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle / reference goldens.
+Runs on a real MI355X only (-m gpu).  Bit-exact for quantiser indices; stated tolerances elsewhere."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import effq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from efficientq_amd.hip_ops import get_ops
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return get_ops("cuda:0")
+
+
+def dev(t):
+    return t.to("cuda:0")
+
+
+# ------------------------------------------------------------------ a1 / a3
+def test_quant_dequant_f32_matches_reference_goldens(ops, gold):
+    g = gold("g1_discretize.npz")
+    alpha = torch.tensor(0.7341)
+    for L in (4, 16, 256):
+        for tag, lo, hi in (("w", -1.0, 1.0), ("a", 0.0, 1.0)):
+            v = T(g[f"L{L}_{tag}_in"])
+            want = T(g[f"L{L}_{tag}_qdq32"])
+            got, idx = ops.quant_dequant_f32(dev(v), dev(alpha), L, lo, hi, want_idx=True)
+            assert torch.equal(got.cpu(), want), (L, tag)
+            want_idx = O.quant_index(v / alpha, L, lo, hi)
+            assert torch.equal(idx.cpu().long(), want_idx)
+            # alpha = 1 reproduces plain discretize (layer_helper.py:25-37)
+            got1 = ops.quant_dequant_f32(dev(v), dev(torch.tensor(1.0)), L, lo, hi)
+            assert torch.equal(got1.cpu(), T(g[f"L{L}_{tag}_q32"]))
+
+
+def test_quant_dequant_ragged_and_empty(ops):
+    gen = torch.Generator().manual_seed(3)
+    for n in (1, 3, 5, 1023, 4097):
+        v = torch.randn(n, generator=gen)
+        a = torch.tensor(0.37)
+        got = ops.quant_dequant_f32(dev(v), dev(a), 16, -1.0, 1.0)
+        assert torch.equal(got.cpu(), O.discretize(v / a, 16, -1, 1) * a)
+    e = ops.quant_dequant_f32(dev(torch.empty(0)), dev(torch.tensor(1.0)), 4, 0.0, 1.0)
+    assert e.numel() == 0
+
+
+# ------------------------------------------------------------------ a2
+@pytest.mark.parametrize("L", [4, 16, 256])
+def test_fit_scale_matches_reference_goldens(ops, gold, L):
+    g = gold("g2_project.npz")
+    for name, lo, hi, to_idx in (("act", 0.0, 1.0, lambda b: torch.round(b * (L - 1))),
+                                 ("wgt", -1.0, 1.0, lambda b: torch.round((b + 1) * (L - 1) / 2))):
+        v = T(g[name])
+        alpha, iters, st = ops.fit_scale(dev(v), L, lo, hi)
+        want_a = float(g[f"{name}_L{L}_alpha"])
+        assert abs(alpha - want_a) <= 1e-11 * abs(want_a), (alpha, want_a)
+        assert iters == int(g[f"{name}_L{L}_iters"])
+        y, b, idx = ops.quant_dequant_f64path(dev(v), st, L, lo, hi, want_b=True, want_idx=True)
+        assert torch.equal(idx.cpu(), T(g[f"{name}_L{L}_idx"]))          # quantiser indices bit-exact
+        assert torch.equal(to_idx(b.cpu()).to(torch.uint8), T(g[f"{name}_L{L}_idx"]))
+        # a*b (EfficientQConv.py:70): python double * fp32 tensor
+        fit = O.fit_scale(v, L, lo, hi)
+        assert torch.equal(b.cpu(), fit.b)
+        assert torch.allclose(y.cpu(), fit.alpha * fit.b, rtol=1e-6, atol=0)
+
+
+def test_fit_scale_with_reducer_equals_unsharded(ops):
+    gen = torch.Generator().manual_seed(11)
+    v = torch.relu(torch.randn(2, 8, 12, 12, 12, generator=gen))
+    a0, it0, _ = ops.fit_scale(dev(v), 4, 0.0, 1.0)
+    a1, it1, _ = ops.fit_scale(dev(v), 4, 0.0, 1.0, reducer=lambda t: t)   # identity all-reduce
+    assert a0 == a1 and it0 == it1
+
+
+def test_fit_scale_raises_at_cap(ops):
+    v = torch.randn(4096, generator=torch.Generator().manual_seed(1))
+    import efficientq_amd.hip_ops as H
+    old = H.ADMM_TOL
+    H.ADMM_TOL = -1.0
+    try:
+        with pytest.raises(RuntimeWarning):
+            ops.fit_scale(dev(v), 4, -1.0, 1.0)
+    finally:
+        H.ADMM_TOL = old
+
+
+def test_moments(ops):
+    gen = torch.Generator().manual_seed(5)
+    for n in (7, 4096, 1 << 20):
+        v = torch.randn(n, generator=gen) * 3 + 0.5
+        m = ops.moments(dev(v)).cpu()
+        vd = v.double()
+        assert m[2].item() == n
+        assert abs(m[0].item() - vd.sum().item()) <= 1e-9 * vd.abs().sum().item()
+        assert abs(m[1].item() - (vd * vd).sum().item()) <= 1e-12 * (vd * vd).sum().item()
+
+
+# ------------------------------------------------------------------ a5 / a6 / a7
+GRAM_CASES = [("k3s1p1", 3, 1, 1), ("k3s221p1", 3, (2, 2, 1), 1), ("k1s1p0", 1, 1, 0),
+              ("k3s1p1_nobias_noatt", 3, 1, 1)]
+
+
+def _ndhwc(t):
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+@pytest.mark.parametrize("tag,k,s,p", GRAM_CASES)
+def test_gram_and_solve_match_reference_goldens(ops, gold, tag, k, s, p):
+    from efficientq_amd.hip_ops import make_geom
+    g = gold("g3g4_gram_solve.npz")
+    x, y, w = T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), T(g[f"{tag}_w"])
+    b = T(g[f"{tag}_b"]) if f"{tag}_b" in g else None
+    att = T(g[f"{tag}_att"]) if f"{tag}_att" in g else None
+    geom = make_geom(x.shape, y.shape[1], k, s, p)
+    A0, B0 = ops.gram(dev(_ndhwc(x)), dev(att) if att is not None else None, dev(_ndhwc(y)), geom, b is not None)
+    wantA, wantB = T(g[f"{tag}_A0"]), T(g[f"{tag}_B0"])
+    # fp32 Gram: summation order differs from the reference's BLAS; tolerance 2e-6 of the matrix scale
+    assert (A0.cpu() - wantA).abs().max() <= 2e-6 * wantA.abs().max()
+    assert (B0.cpu() - wantB).abs().max() <= 2e-6 * wantB.abs().max()
+    assert torch.equal(A0, A0.T)                                   # exactly symmetric
+    # prox solve from the reference's own A0/B0 (isolates the solver): |dW| <= 1e-5 * scale
+    rho, eta = 7.5, 1.3
+    Ainv = ops.spd_inverse(dev(wantA), b is not None, rho, eta)
+    G = T(g[f"{tag}_G"])
+    wstar = torch.empty_like(dev(w))
+    bstar = torch.empty(w.shape[0], device="cuda:0") if b is not None else None
+    ops.prox_solve(dev(wantB), Ainv, dev(w), dev(b) if b is not None else None, dev(G), dev(torch.zeros_like(G)),
+                   rho, eta, wstar, bstar)
+    want_w = T(g[f"{tag}_wstar"])
+    assert (wstar.cpu() - want_w).abs().max() <= 1e-5 * want_w.abs().max()
+    if b is not None:
+        want_b = T(g[f"{tag}_bstar"])
+        assert (bstar.cpu() - want_b).abs().max() <= 1e-5 * max(want_b.abs().max(), want_w.abs().max())
+
+
+@pytest.mark.parametrize("c1,c2,k,s,p,S", [(8, 8, 3, 1, 1, 10), (32, 32, 3, 1, 1, 8), (4, 32, 3, 2, 1, 12),
+                                           (16, 32, 1, 1, 0, 8), (40, 24, 3, 1, 1, 6)])
+def test_gram_vs_oracle(ops, c1, c2, k, s, p, S):
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(c1 * 100 + c2)
+    N = 2
+    x = torch.relu(torch.randn(N, c1, S, S + 1, S + 2, generator=gen))
+    w = torch.randn(c2, c1, k, k, k, generator=gen) * 0.1
+    b = torch.randn(c2, generator=gen)
+    y = F.conv3d(x, w, b, s, p)
+    att = torch.randint(1, 4, y[:, 0].shape, generator=gen).float()
+    ps = O.ProxSystem(x, y, (k, k, k), s, p, w, b, att)
+    geom = make_geom(x.shape, c2, k, s, p)
+    A0, B0 = ops.gram(dev(_ndhwc(x)), dev(att), dev(_ndhwc(y)), geom, True)
+    assert (A0.cpu() - ps.A0).abs().max() <= 3e-6 * ps.A0.abs().max()
+    assert (B0.cpu() - ps.B0).abs().max() <= 3e-6 * ps.B0.abs().max()
+    # sharded accumulation over volumes == unsharded (multi-GPU partial sums)
+    g1 = make_geom(x[:1].shape, c2, k, s, p)
+    A1, B1 = ops.gram(dev(_ndhwc(x[:1])), dev(att[:1]), dev(_ndhwc(y[:1])), g1, True)
+    A1, B1 = ops.gram(dev(_ndhwc(x[1:])), dev(att[1:]), dev(_ndhwc(y[1:])), g1, True, A1, B1)
+    assert (A1 - A0).abs().max() <= 3e-6 * ps.A0.abs().max()
+    assert (B1 - B0).abs().max() <= 3e-6 * ps.B0.abs().max()
+
+
+@pytest.mark.parametrize("n,c2", [(28, 8), (217, 16), (865, 32), (130, 64)])
+def test_spd_inverse_and_prox(ops, n, c2):
+    gen = torch.Generator().manual_seed(n)
+    X = torch.randn(n, 3 * n, generator=gen)
+    A0 = (2 * X @ X.T).float()
+    rho, eta = 30.0, 3.0
+    A = A0.double().clone()
+    d = torch.full((n,), rho + eta, dtype=torch.float64)
+    d[-1] = eta
+    A += torch.diag(d)
+    Ainv = ops.spd_inverse(dev(A0), True, rho, eta).cpu()
+    want = torch.linalg.inv(A)
+    assert (Ainv.double() - want).abs().max() <= 2e-7 * want.abs().max() + 1e-12
+    B0 = torch.randn(c2, n, generator=gen) * 10
+    W0 = torch.randn(c2, n - 1, generator=gen)
+    b0 = torch.randn(c2, generator=gen)
+    G = torch.randn(c2, n - 1, generator=gen)
+    dual = torch.randn(c2, n - 1, generator=gen) * 0.1
+    wstar = torch.empty(c2, n - 1, device="cuda:0")
+    bstar = torch.empty(c2, device="cuda:0")
+    ops.prox_solve(dev(B0), dev(Ainv), dev(W0), dev(b0), dev(G), dev(dual), rho, eta, wstar, bstar)
+    Bm = B0.double() + eta * torch.cat([W0, b0[:, None]], 1).double()
+    Bm[:, :-1] += rho * (G - dual).double()
+    wantW = torch.linalg.solve(A, Bm.T).T
+    got = torch.cat([wstar.cpu(), bstar.cpu()[:, None]], 1).double()
+    assert (got - wantW).abs().max() <= 2e-5 * wantW.abs().max()
+
+
+# ------------------------------------------------------------------ the conv entry point
+CONV_CASES = [
+    # c1, c2, k, stride, pad, spatial
+    (32, 32, 3, 1, 1, (8, 8, 16)),
+    (8, 8, 3, 1, 1, (9, 7, 11)),        # ragged tiles
+    (4, 32, 3, 2, 1, (16, 16, 16)),     # first layer, stride 2
+    (1, 8, 3, 1, 1, (8, 8, 8)),         # single modality
+    (2, 8, 3, (2, 2, 1), 1, (10, 12, 9)),
+    (64, 128, 1, 1, 0, (4, 4, 8)),      # 1x1x1
+    (32, 3, 1, 1, 0, (8, 8, 8)),        # classifier
+    (64, 64, 3, 1, 1, (4, 8, 8)),       # two channel slabs
+    (48, 40, 3, 1, 1, (4, 4, 8)),       # odd widths
+]
+
+
+@pytest.mark.parametrize("c1,c2,k,s,p,sp", CONV_CASES)
+def test_conv_step_vs_torch_fp32(ops, c1, c2, k, s, p, sp):
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(c1 * 1000 + c2 + k)
+    N = 2
+    x = torch.relu(torch.randn(N, c1, *sp, generator=gen))
+    w = torch.randn(c2, c1, k, k, k, generator=gen) * (1.0 / (c1 * k ** 3) ** 0.5)
+    b = torch.randn(c2, generator=gen) * 0.1
+    ref = F.conv3d(x, w, b, s, p)
+    y = ref + 0.1 * torch.randn(ref.shape, generator=gen)
+    att = torch.randint(1, 4, y[:, 0].shape, generator=gen).float()
+    geom = make_geom(x.shape, c2, k, s, p)
+    out, sq = ops.conv_step(dev(_ndhwc(x)), dev(w), dev(b), geom, dev(_ndhwc(y)), dev(att), want_out=True)
+    got = out.permute(0, 4, 1, 2, 3).cpu()
+    # fp32 fma chains in a different order than oneDNN: 1e-5 of the output scale
+    assert (got - ref).abs().max() <= 1e-5 * ref.abs().max()
+    d2 = (ref.double() - y.double()) ** 2
+    sq = sq.cpu()
+    assert abs(sq[0].item() - d2.sum().item()) <= 1e-5 * d2.sum().item()
+    assert abs(sq[1].item() - (att[:, None].double() * d2).sum().item()) <= 1e-5 * (att[:, None] * d2).sum().item()
+    # loss-only call (no output tensor) and no-mask call agree with the fused one
+    _, sq2 = ops.conv_step(dev(_ndhwc(x)), dev(w), dev(b), geom, dev(_ndhwc(y)), None)
+    sq2 = sq2.cpu()
+    assert sq2[0].item() == sq[0].item() and sq2[1].item() == sq2[0].item()
+    # bias-free forward
+    out3, _ = ops.conv_step(dev(_ndhwc(x)), dev(w), None, geom, want_out=True)
+    ref3 = F.conv3d(x, w, None, s, p)
+    assert (out3.permute(0, 4, 1, 2, 3).cpu() - ref3).abs().max() <= 1e-5 * ref3.abs().max()
+
+
+def test_conv_step_fused_act_quant_matches_quantized_forward(ops):
+    """PTQConv.forward in quantized mode (PTQConv.py:163-167): quantiser indices bit-exact, so the
+    fused path must equal conv(quant_dequant_f32(x)) exactly (same kernel, same fma order)."""
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(77)
+    x = torch.relu(torch.randn(2, 16, 8, 8, 8, generator=gen))
+    w = torch.randn(16, 16, 3, 3, 3, generator=gen) * 0.05
+    b = torch.randn(16, generator=gen) * 0.1
+    alpha = torch.tensor(0.8123)
+    geom = make_geom(x.shape, 16, 3, 1, 1)
+    xq = ops.quant_dequant_f32(dev(_ndhwc(x)), dev(alpha), 4, 0.0, 1.0)
+    a, _ = ops.conv_step(xq, dev(w), dev(b), geom, want_out=True)
+    f, _ = ops.conv_step(dev(_ndhwc(x)), dev(w), dev(b), geom, act_alpha=dev(alpha), act_levels=4, want_out=True)
+    assert torch.equal(a, f)
+    ref = O.quantized_forward(x, w, b, alpha, 4, True, 1, 1)
+    assert (f.permute(0, 4, 1, 2, 3).cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+def test_reductions_are_run_to_run_deterministic(ops):
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(9)
+    x = torch.relu(torch.randn(2, 32, 8, 16, 16, generator=gen))
+    w = torch.randn(32, 32, 3, 3, 3, generator=gen) * 0.03
+    y = torch.randn(2, 32, 8, 16, 16, generator=gen)
+    geom = make_geom(x.shape, 32, 3, 1, 1)
+    xs, ys, ws = dev(_ndhwc(x)), dev(_ndhwc(y)), dev(w)
+    vals = {tuple(ops.conv_step(xs, ws, None, geom, ys)[1].cpu().tolist()) for _ in range(5)}
+    assert len(vals) == 1
+    ms = {tuple(ops.moments(xs).cpu().tolist()) for _ in range(5)}
+    assert len(ms) == 1
