@@ -1,0 +1,294 @@
+"""Quantised Conv3d modules with the reference's class contract, computing on MI355X.
+
+``PTQConv`` mirrors the reference base class (src/models/PTQConv.py:11-174): same
+constructor, parameters (``weight``, ``bias``, 0-dim ``alpha_act``/``alpha_w``), mode
+setters, ``forward`` dispatch, ``store_int_weight``/``restore_fp_weight``.
+``EfficientQConvHIP`` mirrors ``EfficientQConv.ptq`` (src/models/EfficientQConv.py:33-166):
+the layer-wise ADMM calibration, with every tensor computation issued through the C-ABI
+library (``hip_ops``).  torch supplies memory, streams and the collective only.
+
+Both class names contain ``QConv`` because the reference finds quantised layers by
+class-name substring (src/models/model_blk.py:26-34).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import hip_ops
+from .hip_ops import from_ndhwc, make_geom, to_ndhwc
+
+# ADMM constants are constructor constants in the reference (EfficientQConv.py:23-26)
+LWQ_ITER, LWQ_RHO, LWQ_RHO_MAX, LWQ_ETA, RHO_PERIOD = 200, 10.0, 1000.0, 1.0, 50
+
+
+def get_ops(device):
+    """Indirection point: tests substitute a CPU stand-in built on the oracle here."""
+    return hip_ops.get_ops(device)
+
+
+class SumReducer:
+    """Data-parallel SUM over calibration-volume shards (RCCL all-reduce; identity on one rank)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+
+    def __call__(self, t: torch.Tensor) -> torch.Tensor:
+        if self.on:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def __bool__(self):
+        return self.on
+
+
+class PTQConv(nn.Conv3d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, q_weight=True, qlvl=8, q_act=True, qlvl_act=8, **kwQ):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        if self.dilation != (1, 1, 1) or self.groups != 1:
+            # the reference's solver ignores both (solver.py:86-111); both shipped configs use 1
+            raise NotImplementedError("dilation/groups other than 1 are outside the calibrated path")
+        self.conv_param = dict(stride=stride, padding=padding, dilation=dilation, groups=groups)
+        self.q_act, self.q_weight = q_act, q_weight
+        self.qlvl_w, self.qlvl_act = qlvl, qlvl_act
+        self.kwQ = kwQ
+        self.alpha_act = nn.Parameter(torch.tensor(1.))
+        self.alpha_w = nn.Parameter(torch.tensor(1.))
+        self.output_fp = None            # FP target, set by the forward hook
+        self.name = None
+        self.snap_dir = kwQ.get('snap_dir', None)
+        self.w_backup = self.b_backup = None
+        self._act_inited = False
+        self.set_fp()
+
+    # ---- mode flags (PTQConv.py:50-72) --------------------------------------------------------
+    def _mode(self, fp=False, quantizing=False, quantized=False, init_act=False):
+        self._fp, self._quantizing, self._quantized, self._init_act = fp, quantizing, quantized, init_act
+
+    def set_fp(self):
+        self._mode(fp=True)
+
+    def set_quantizing(self):
+        self._mode(quantizing=True)
+
+    def set_quantized(self):
+        self._mode(quantized=True)
+
+    def set_init_act(self):
+        self._mode(init_act=True)
+
+    def qweight_init_iter(self):
+        pass
+
+    def qparam_init(self):
+        pass
+
+    def perform_quantization(self):
+        pass
+
+    def backup_weight(self):
+        self.w_backup = self.weight.data.cpu().clone()
+        if self.bias is not None:
+            self.b_backup = self.bias.data.cpu().clone()
+
+    # ---- device helpers ------------------------------------------------------------------------
+    def _geom(self, x):
+        return make_geom(x.shape, self.out_channels, self.kernel_size, self.stride, self.padding)
+
+    def _conv(self, x, quantize_act: bool):
+        """conv3d (optionally with the fp32 activation quant-dequant fused into the tile load)."""
+        ops = get_ops(x.device)
+        out, _ = ops.conv_step(to_ndhwc(x.detach()), self.weight.data, None if self.bias is None else self.bias.data,
+                               self._geom(x), act_alpha=self.alpha_act.data if quantize_act else None,
+                               act_levels=self.qlvl_act if quantize_act else 0, want_out=True)
+        return from_ndhwc(out)
+
+    def _quantize_act(self, x):
+        """discretize(x/alpha_act, L, 0, 1) * alpha_act in fp32 (PTQConv.py:114-116)."""
+        ops = get_ops(x.device)
+        return from_ndhwc(ops.quant_dequant_f32(to_ndhwc(x.detach()), self.alpha_act.data, self.qlvl_act, 0.0, 1.0))
+
+    def _quantize_w(self):
+        ops = get_ops(self.weight.device)
+        return ops.quant_dequant_f32(self.weight.data, self.alpha_w.data, self.qlvl_w, -1.0, 1.0)
+
+    def init_alpha_act(self, x):
+        """PTQConv.py:74-78."""
+        ops = get_ops(x.device)
+        xn = to_ndhwc(x.detach())
+        a, _, st = ops.fit_scale(xn, self.qlvl_act, 0.0, 1.0, reducer=SumReducer() or None)
+        self.alpha_act.data = torch.tensor(a, device=x.device)
+        self._act_inited = True
+        y, _, _ = ops.quant_dequant_f64path(xn, st, self.qlvl_act, 0.0, 1.0)
+        return from_ndhwc(y)
+
+    def ptq(self, x):
+        raise NotImplementedError
+
+    # ---- storage formats (PTQConv.py:125-152) -----------------------------------------------
+    def store_int_weight(self):
+        """Level ids as uint8 (<=256 levels) / int32, for storage only.  Uses the saved alpha_w,
+        which is the LAST iterate's scale while weight is the BEST iterate's (quirk Q6)."""
+        a = self.alpha_w.data
+        b = self.weight.data / a
+        delta = 2 / (self.qlvl_w - 1)
+        w_int = torch.round((b + 1) / delta)
+        w_int = w_int.to(torch.uint8) if self.qlvl_w <= 256 else w_int.to(torch.int32)
+        self.weight.requires_grad = False
+        self.weight.data = w_int.data.cpu()
+
+    def restore_fp_weight(self):
+        delta = 2 / (self.qlvl_w - 1)
+        b = self.weight.data.float() * delta - 1
+        self.weight.data = self.alpha_w.data * b
+
+    # ---- forward dispatch (PTQConv.py:154-174) ----------------------------------------------
+    def forward(self, x):
+        if self._fp:
+            return self._conv(x, False)
+        if self._quantizing:
+            self.ptq(x)
+            return self._conv(x, self.q_act)
+        if self._quantized:
+            return self._conv(x, self.q_act)
+        if self._init_act:
+            qact = self.init_alpha_act(x)
+            return self._conv(qact, False)
+        raise RuntimeError(f"Unknown FP/Quant setting: FP={self._fp}, "
+                           f"Quantizing={self._quantizing}, Quantized={self._quantized}")
+
+
+class EfficientQConvHIP(PTQConv):
+    """Layer-wise ADMM calibrator (EfficientQConv.py:13-166) on the HIP library."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, q_weight=True, qlvl=8, q_act=True, qlvl_act=8, **kwQ):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         q_weight, qlvl, q_act, qlvl_act, **kwQ)
+        self.lwq_iter, self.lwq_rho, self.lwq_rho_max, self.lwq_eta = LWQ_ITER, LWQ_RHO, LWQ_RHO_MAX, LWQ_ETA
+        self.lwq_fold_bn = True
+        self.lwq_verbose = kwQ.get('lwq_verbose', False)
+        self.mask_pyramid = None
+        self.layer_loss = None
+        self.last_trace = None          # diagnostics of the last calibration (not in the reference)
+
+    @staticmethod
+    def _std(m: torch.Tensor) -> float:
+        """Unbiased std from [sum, sumsq, n] (Tensor.std(), EfficientQConv.py:46,48)."""
+        s, ss, n = m.tolist()
+        return math.sqrt(max(ss - s * s / n, 0.0) / (n - 1))
+
+    def ptq(self, x):
+        ops = get_ops(x.device)
+        red = SumReducer()
+        dev = x.device
+        xn = to_ndhwc(x.detach())
+        yn = to_ndhwc(self.output_fp.detach().to(dev))
+        geom = self._geom(x)
+        W0 = self.weight.data.contiguous()
+        has_b = self.bias is not None
+        b0 = self.bias.data.contiguous() if has_b else None
+        c2 = self.out_channels
+        nw = W0.numel() // c2
+
+        # rho_scale = max(numel(y)*std(y) / (numel(W)*std(W)), 1)          (EfficientQConv.py:43-49)
+        my = red(ops.moments(yn))
+        mw = ops.moments(W0)
+        y_dim = my[2].item()
+        rho_scale = max(y_dim * self._std(my) / (W0.numel() * self._std(mw)), 1.0)
+
+        att = None
+        if self.lwq_verbose:
+            print(f'Calibrating {self.name}')
+        if self.mask_pyramid:                                              # (:51-62)
+            for mask in self.mask_pyramid:
+                if tuple(mask.shape[1:]) == tuple(self.output_fp.shape[2:]):
+                    att = mask.to(dev).contiguous()
+                    break
+        if att is not None:
+            ma = red(ops.moments(att))
+            rho_scale *= ma[0].item() / ma[2].item()
+
+        act_iters = 0
+        if self.q_act:                                                     # (:64-72)
+            if self._act_inited:
+                xq = to_ndhwc(self._quantize_act(x))
+            else:
+                a_act, act_iters, st = ops.fit_scale(xn, self.qlvl_act, 0.0, 1.0, reducer=red or None,
+                                                     guess_iters=12 * self.qlvl_act)
+                self.alpha_act.data = torch.tensor(a_act, dtype=x.dtype, device=dev)
+                xq, _, _ = ops.quant_dequant_f64path(xn, st, self.qlvl_act, 0.0, 1.0)
+        else:
+            xq = xn
+
+        rho = self.lwq_rho * rho_scale                                    # (:74-76)
+        rho_m = self.lwq_rho_max * rho_scale
+        eta = self.lwq_eta * rho_scale
+
+        A0, B0 = ops.gram(xq, att, yn, geom, has_b)                        # (:87-91, solver.py:282-314)
+        red(A0)
+        red(B0)
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        G = W0.clone()
+        dual = torch.zeros_like(W0)
+        wstar = torch.empty_like(W0)
+        v = torch.empty_like(W0)
+        bstar = torch.empty(c2, **f32) if has_b else None
+        best_G = torch.empty_like(W0)
+        best_b = torch.empty(c2, **f32) if has_b else None
+        sqerr = torch.zeros(2, dtype=torch.float64, device=dev)
+        best = torch.zeros(2, dtype=torch.float64, device=dev)
+        st_w = ops.new_fp_state()
+        Ainv, rho_of_inv = None, None
+        guess = 16
+        a_w = 1.0
+        w_iters = []
+        for i in range(self.lwq_iter):                                     # (:99-144)
+            if rho_of_inv != rho:      # A changes only with rho: 5 inverses per layer, not 200 LU solves
+                Ainv = ops.spd_inverse(A0, has_b, rho, eta, out=Ainv)
+                rho_of_inv = rho
+            ops.prox_solve(B0, Ainv, W0, b0, G, dual, rho, eta, wstar, bstar)
+            ops.admm_presum(wstar, dual, v)
+            a_w, it_w, _ = ops.fit_scale(v, self.qlvl_w, -1.0, 1.0, guess_iters=guess, state=st_w)
+            guess = it_w + 2
+            w_iters.append(it_w)
+            dual_div = 1.0
+            if i % RHO_PERIOD == 0:                                        # (:129-137)
+                dual_div = 2.0 if rho * 2 <= rho_m else rho_m / rho
+            ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div)
+            ops.conv_step(xq, G, bstar, geom, yn, None, sqerr=sqerr)       # unweighted MSE (quirk Q5)
+            red(sqerr)
+            ops.admm_keep_best(sqerr, best, i, G, bstar, best_G, best_b)
+            if i % RHO_PERIOD == 0:
+                rho = rho * 2 if rho * 2 <= rho_m else rho_m
+
+        self.weight.data = best_G.reshape(self.weight.shape)               # (:147-158)
+        if has_b:
+            self.bias.data = best_b
+        self.alpha_w.data = torch.tensor(a_w, dtype=x.dtype, device=dev)   # LAST iterate's scale (quirk Q6)
+
+        _, fin = ops.conv_step(xq, best_G, best_b, geom, yn, att)          # (:161-166)
+        red(fin)
+        fin_h, best_h = fin.tolist(), best.tolist()
+        numel = y_dim * 1.0
+        lossf = (fin_h[1] if att is not None else fin_h[0]) / numel
+        if self.layer_loss is not None:
+            self.layer_loss.append(f'{self.name:45s}:{lossf}')
+        self.last_trace = dict(rho_scale=rho_scale, best_iter=int(best_h[1]), best_mse=best_h[0] / numel,
+                               final_mse=fin_h[0] / numel, layer_loss=lossf, act_iters=act_iters,
+                               w_iters=w_iters, alpha_w=a_w)
+
+    def compute_quant_error(self, output_fp, Qw, Qact):
+        """EfficientQConv.py:168-172."""
+        ops = get_ops(Qact.device)
+        _, sq = ops.conv_step(to_ndhwc(Qact), Qw, None if self.bias is None else self.bias.data,
+                              self._geom(Qact), to_ndhwc(output_fp))
+        return sq[0].item() / output_fp.numel()

@@ -1,0 +1,257 @@
+"""Host logic of the product (qconv / unet / calibrate / config) on the CPU, driven through the
+test-only oracle backend (tests/cpu_backend.py) and checked against reference goldens.
+Also: the C-ABI library loads and exports every declared symbol (no compute without a GPU)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from tests import cpu_backend
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = lambda a: torch.from_numpy(np.array(a)).clone()
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from efficientq_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "effq_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(effq_\w+|conv3d_quant_calib_step)\s*\(", hdr))
+    declared -= {"effq_geom", "effq_fp_state"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                      # raises if the .so is missing or a symbol is not exported
+    assert lib.effq_version() >= 100
+    assert lib.effq_reduce_ws_bytes() > 0
+
+
+def test_product_path_refuses_cpu_tensors():
+    from efficientq_amd import hip_ops, _lib
+    with pytest.raises(_lib.EffqError):
+        hip_ops.get_ops("cpu")
+    from efficientq_amd.qconv import EfficientQConvHIP
+    conv = EfficientQConvHIP(2, 2, 3, 1, 1)
+    with pytest.raises(_lib.EffqError):
+        conv(torch.zeros(1, 2, 4, 4, 4))
+
+
+# ------------------------------------------------------------------ graph / state_dict / BN fold / masks
+def _tiny(task, L=4):
+    from efficientq_amd import config as Cf
+    if task == "lits":
+        args = Cf.make_args(Cf.TINY_NET, L, L, lwq_batchsz=2)
+    else:
+        net = dict(Cf.TINY_NET, task="brats", nMod=2, nClass=4, multi_label="brats", init_stride="2,2,2")
+        args = Cf.make_args(net, L, L, lwq_batchsz=2)
+    QConv, info, kwQ = Cf.get_conv_class(args)
+    cube, _ = Cf.get_model_cube(args, QConv, kwQ)
+    return args, cube["model"], info
+
+
+@pytest.mark.parametrize("task,fname", [("lits", "g6_tiny_lits_L4.npz"), ("brats", "g6_tiny_brats_L4.npz")])
+def test_state_dict_keys_match_reference(gold, task, fname):
+    g = gold(fname)
+    args, model, info = _tiny(task)
+    want = {k[4:]: g[k].shape for k in g.files if k.startswith("sd0/")}
+    got = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert set(got) == set(want)
+    assert all(tuple(want[k]) == got[k] for k in want)
+    assert info == "effq_bothQw4a4"
+
+
+def test_full_size_nets_have_the_surveyed_layer_counts():
+    from efficientq_amd import config as Cf
+    from efficientq_amd.qconv import PTQConv
+    for net, nq, npar in ((Cf.BRATS_NET, 22, 5.96e6), (Cf.LITS_NET, 28, 23.9e6)):
+        args = Cf.make_args(net, 4, 4)
+        QConv, _, kwQ = Cf.get_conv_class(args)
+        model = Cf.get_model_cube(args, QConv, kwQ)[0]["model"]
+        qs = [m for m in model.modules() if isinstance(m, PTQConv)]
+        assert len(qs) == nq
+        assert abs(sum(p.numel() for p in model.parameters()) - npar) / npar < 0.02
+        assert qs[0].qlvl_w == 256 and not qs[0].q_act and qs[-1].qlvl_w == 256 and not qs[-1].q_act
+        assert qs[1].qlvl_w == 4 and qs[1].q_act and qs[1].qlvl_act == 4
+
+
+def test_bn_fold_matches_reference(gold):
+    from efficientq_amd.unet import ConvUnit
+    from efficientq_amd.calibrate import search_fold_and_remove_bn
+    g = gold("g7_bnfold.npz")
+    blk = ConvUnit("mid", 4, 6, 3, 1, 1, 1, nn.Conv3d, nn.BatchNorm3d, True, 0)
+    with torch.no_grad():
+        blk.conv.weight.copy_(T(g["w"]))
+        blk.bn.weight.copy_(T(g["gamma"])); blk.bn.bias.copy_(T(g["beta"]))
+        blk.bn.running_mean.copy_(T(g["mean"])); blk.bn.running_var.copy_(T(g["var"]))
+    blk.eval()
+    assert torch.equal(blk(T(g["x"])), T(g["y_before"]))
+    search_fold_and_remove_bn(blk)
+    assert torch.equal(blk.conv.weight.data, T(g["w_fold"]))
+    assert torch.equal(blk.conv.bias.data, T(g["b_fold"]))
+    assert torch.equal(blk(T(g["x"])), T(g["y_after"]))
+
+
+def test_resunit_inplace_relu_residual(gold):
+    from efficientq_amd.unet import ResUnit
+    g = gold("g10_resblock_mid.npz")
+    rb = ResUnit("mid", 4, 4, 0.5, 1, nn.Conv3d, nn.BatchNorm3d)
+    rb.load_state_dict({k[3:]: T(g[k]) for k in g.files if k.startswith("sd/")})
+    rb.eval()
+    assert torch.equal(rb(T(g["x"])), T(g["y"]))
+
+
+@pytest.mark.parametrize("task", ["lits", "brats"])
+def test_attention_masks_match_reference(gold, task):
+    from efficientq_amd import calibrate as K
+    g = gold("g8_attmask.npz")
+    for key, st in ((f"{task}_s1", "1"), (f"{task}_s2", "2,2,2")):
+        logits, data = T(g[f"{key}_logits"]), T(g[f"{key}_data"])
+        ones = torch.ones_like(data[:, 0]).bool()
+        body = (data[:, 0] != 0).bool() if task == "brats" else ones
+        wmap, nums = K.get_att_weight_map(logits, ones, "p:0.5", task=task)
+        assert nums == g[f"{key}_nums"].tolist()
+        assert [wmap[i] for i in range(len(wmap))] == g[f"{key}_wvals"].tolist()
+        pyr = K.get_mask_pyramid(logits, body, wmap, st, num_lvls=3, task=task)
+        for i, m in enumerate(pyr):
+            assert torch.equal(m, T(g[f"{key}_pyr{i}"]).float())
+
+
+def test_int_weight_storage_roundtrip(gold):
+    from efficientq_amd.qconv import PTQConv
+    g = gold("g9_intweight.npz")
+    for L in (4, 16, 256):
+        conv = PTQConv(4, 6, 3, 1, 1, qlvl=L)
+        conv.weight.data = T(g[f"L{L}_q"])
+        conv.alpha_w.data = T(g[f"L{L}_alpha"])
+        conv.store_int_weight()
+        assert conv.weight.data.dtype == torch.uint8 and torch.equal(conv.weight.data, T(g[f"L{L}_int"]))
+        conv.restore_fp_weight()
+        assert torch.equal(conv.weight.data, T(g[f"L{L}_restored"]))
+
+
+def test_center_crop_pads_and_crops():
+    from efficientq_amd.calibrate import center_crop
+    t = torch.arange(2 * 5 * 6 * 7, dtype=torch.float32).reshape(2, 5, 6, 7)
+    c = center_crop(t, (3, 4, 5))
+    assert torch.equal(c, t[:, 1:4, 1:5, 1:6])
+    p = center_crop(t, (8, 6, 7))
+    assert p.shape == (2, 8, 6, 7) and torch.equal(p[:, 1:6], t) and p[:, 0].abs().sum() == 0
+
+
+# ------------------------------------------------------------------ layer calibration through the product's ptq()
+def _layer_from_gold(g, tag):
+    from efficientq_amd.qconv import EfficientQConvHIP
+    c1, c2, k, pad, N, S, L_w, L_a, q_act, with_mask = [int(v) for v in g[f"{tag}_meta"]]
+    stride = tuple(int(v) for v in g[f"{tag}_stride"])
+    conv = EfficientQConvHIP(c1, c2, k, stride, pad, 1, 1, True, q_weight=True, qlvl=L_w, q_act=bool(q_act),
+                             qlvl_act=L_a)
+    conv.weight.data = T(g[f"{tag}_w_in"])
+    conv.bias.data = T(g[f"{tag}_b_in"])
+    conv.output_fp = T(g[f"{tag}_y"])
+    conv.name = "layer"
+    conv.layer_loss = []
+    if with_mask:
+        y = conv.output_fp
+        conv.mask_pyramid = [torch.ones(N, *[d // 2 for d in y.shape[2:]]), T(g[f"{tag}_mask_full"])]
+    return conv, T(g[f"{tag}_x"]), (L_w, L_a, bool(q_act))
+
+
+@pytest.mark.parametrize("tag", ["L4", "L16", "first", "k1"])
+def test_product_ptq_on_oracle_backend_matches_reference(gold, monkeypatch, tag):
+    cpu_backend.install(monkeypatch)
+    g = gold("g5_layer_ptq.npz")
+    conv, x, (L_w, L_a, q_act) = _layer_from_gold(g, tag)
+    conv.set_quantizing()
+    with torch.no_grad():
+        out = conv(x)
+    want_loss = float(g[f"{tag}_layer_loss"])
+    got_loss = float(conv.layer_loss[0].split(":")[1])
+    assert abs(got_loss - want_loss) <= 1e-6 * want_loss
+    assert conv.layer_loss[0].startswith(f"{'layer':45s}:")
+    # the stand-in's conv runs on channels-last memory, so the per-iteration losses differ in the last
+    # ulp and the best iterate may be another point of the same plateau: indices must agree
+    # exactly, values to fp32 rounding
+    wg = T(g[f"{tag}_weight"])
+    lv = lambda t: torch.round((t / t.abs().max() + 1) * (L_w - 1) / 2)
+    assert torch.equal(lv(conv.weight.data), lv(wg))
+    assert (conv.weight.data - wg).abs().max() <= 2e-6 * wg.abs().max()
+    assert (conv.bias.data - T(g[f"{tag}_bias"])).abs().max() <= 1e-3 * T(g[f"{tag}_bias"]).abs().max()  # b* of another plateau iterate
+    assert abs(conv.alpha_w.data.item() - float(g[f"{tag}_alpha_w"])) <= 2e-6 * float(g[f"{tag}_alpha_w"])
+    if q_act:
+        assert conv.alpha_act.data.item() == float(g[f"{tag}_alpha_act"])
+    assert (out - T(g[f"{tag}_fwd_q"])).abs().max() <= 1e-4 * T(g[f"{tag}_fwd_q"]).abs().max()
+
+
+# ------------------------------------------------------------------ whole do_ptq window on the tiny nets
+def _run_tiny(task, fname, gold, monkeypatch):
+    from efficientq_amd import calibrate as K
+    cpu_backend.install(monkeypatch)
+    g = gold(fname)
+    args, model, _ = _tiny(task)
+    model.load_state_dict({k[4:]: T(g[k]) for k in g.files if k.startswith("sd0/")}, strict=False)
+    model.eval()
+    K.search_fold_and_remove_bn(model)
+    S = int(g["meta"][1])
+    nmod = 1 if task == "lits" else 2
+    vols = torch.randn(2, nmod, S, S, S, generator=torch.Generator().manual_seed(int(g["vols_seed"])))
+    if task == "brats":
+        zz = torch.arange(S).float() - (S - 1) / 2
+        r = (zz[:, None, None] ** 2 + zz[None, :, None] ** 2 + zz[None, None, :] ** 2).sqrt()
+        vols = vols * (r < 0.45 * S).float()
+    assert torch.equal(vols[:, :, ::8, ::8, ::8], T(g["vols_check"]))
+    K.set_name(model)
+    res = K.calibrate_model(model, vols, task, args.init_stride)
+    return g, model, res
+
+
+@pytest.mark.parametrize("task,fname", [("brats", "g6_tiny_brats_L4.npz")])
+def test_whole_calibration_on_oracle_backend_matches_reference(gold, monkeypatch, task, fname):
+    g, model, res = _run_tiny(task, fname, gold, monkeypatch)
+    names = [l.split(":")[0].strip() for l in res["layer_loss"]]
+    assert names == g["layer_names"].tolist()
+    got = np.array([float(l.split(":")[1]) for l in res["layer_loss"]])
+    assert res["nums"] == g["class_nums"].tolist()
+    for i, m in enumerate(res["pyramid"]):
+        assert torch.equal(m, T(g[f"pyr{i}"]).float())
+    # Layer-level parity (1e-3 relative MSE on IDENTICAL inputs) is pinned by the g5 tests above.  In the
+    # whole-net run each layer is calibrated on the quantised upstream's output, so once one layer keeps a
+    # different iterate of its loss plateau (last-ulp loss differences) the inputs of all later layers
+    # differ and their losses drift at the percent level, in both directions (hard parts).
+    want = g["layer_loss"]
+    assert np.all(np.abs(got[:3] - want[:3]) <= 1e-5 * want[:3]), (got, want)
+    assert np.all(np.abs(got - want) <= 5e-2 * want), (got, want)
+    assert abs(got.sum() - want.sum()) <= 3e-2 * want.sum()
+    sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4), slice(None, None, 4))
+    assert torch.allclose(res["output_fp"][-1][sub], T(g["output_fp_sub"]), atol=1e-5)
+    oq, oq_ref = res["output_q"][-1][sub], T(g["output_q_sub"])
+    assert ((oq - oq_ref) ** 2).mean() <= 2e-2 * (oq_ref ** 2).mean()
+    # model-level agreement of the quantised with the FP prediction (Dice proxy) within 0.5 pt
+    agree = ((res["output_q"][-1] > 0) == (res["output_fp"][-1] > 0)).float().mean().item()
+    assert abs(agree - float(g["agree"])) <= 5e-3
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("sdq/") and k.endswith("alpha_w") and ("conv0" in k or "UResBlock1" in k):
+            assert abs(sd[k[4:]].item() - float(g[k])) <= 1e-4 * abs(float(g[k])), k
+
+
+# ------------------------------------------------------------------ data-parallel (gloo, world_size 2)
+def test_data_parallel_two_ranks_gloo_matches_single_rank(tmp_path):
+    script = os.path.join(ROOT, "tests", "dp_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+    out = str(tmp_path / "dp")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", script, out],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    single = torch.load(out + "_single.pt")
+    dp0, dp1 = torch.load(out + "_rank0.pt"), torch.load(out + "_rank1.pt")
+    # replicas stay in lock step: identical weights on both ranks
+    for k in dp0["sd"]:
+        assert torch.equal(dp0["sd"][k], dp1["sd"][k]), k
+    assert dp0["nums"] == single["nums"]
+    a, b = np.array(dp0["loss"]), np.array(single["loss"])
+    assert np.all(np.abs(a - b) <= 1e-3 * b), (a, b)
