@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (libamdhip64.so.7).  It must be mapped BEFORE libeffq_hip.so so
+# that both share ONE runtime instance (same SONAME => the loader reuses it); loading ours first
+# would pull /opt/rocm's copy and leave two runtimes in the process ("no ROCm-capable device").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeffq_hip.so")
 

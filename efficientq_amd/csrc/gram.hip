@@ -9,7 +9,7 @@
 // Each workgroup streams its voxel range in chunks of KC voxels: the two 128-row panels are
 // gathered (coalesced along channels) into LDS as [voxel][row], and the 4 waves run
 // v_mfma_f32_32x32x2_f32 with K = voxels.  Partial blocks go to per-split slabs; a second
-// kernel adds the slabs in fp64 in a fixed order (deterministic), mirrors, scales by 2 and
+// kernel adds the (fp64) slabs in a fixed order (deterministic), mirrors, scales by 2 and
 // scatters into the reference's (c,kd,kh,kw)+bias row order.
 #include "common.h"
 
@@ -31,7 +31,7 @@ struct GramParams {
   long long V;
   int nsplit;
   long long vox_per_split;
-  float* slabs;
+  double* slabs;
 };
 
 struct VoxInfo {
@@ -95,11 +95,15 @@ __global__ __launch_bounds__(256) void k_gram(GramParams p) {
   decode(I * MB + row_local, kindI, kdI, khI, kwI, cI);
   decode(J * MB + row_local, kindJ, kdJ, khJ, kwJ, cJ);
 
-  f32x16 acc[4];
+  // fp32 MFMA accumulation runs over ONE chunk (KC voxels) only and is then folded into fp64
+  // accumulators: the normal equations are ill-conditioned (cond ~1e3-1e6, and the bias column is
+  // nearly collinear with the non-negative activations), so a 1e-7 relative error in A0 moves the
+  // ADMM losses at the 1e-3 level.  With the fold the Gram is accurate to ~1e-9 at full size.
+  double acc64[4][16];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc64[jt][r] = 0.0;
 
   const long long v_begin = (long long)blockIdx.y * p.vox_per_split;
   long long v_end = v_begin + p.vox_per_split;
@@ -139,6 +143,11 @@ __global__ __launch_bounds__(256) void k_gram(GramParams p) {
       if (!diag) panJ[vv * PS + row_local] = gram_fetch(p, kindJ, kdJ, khJ, kwJ, cJ, vi, v0 + vv);
     }
     __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
 #pragma unroll 4
     for (int s = 0; s < KC / 2; ++s) {
       const int vv = 2 * s + lh;
@@ -149,15 +158,19 @@ __global__ __launch_bounds__(256) void k_gram(GramParams p) {
         acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[jt], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc64[jt][r] += (double)acc[jt][r];
   }
 
-  float* dst = p.slabs + ((size_t)blockIdx.y * p.npairs + blockIdx.x) * (size_t)(MB * MB);
+  double* dst = p.slabs + ((size_t)blockIdx.y * p.npairs + blockIdx.x) * (size_t)(MB * MB);
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      dst[(size_t)(wid * 32 + i) * MB + jt * 32 + li] = acc[jt][r];
+      dst[(size_t)(wid * 32 + i) * MB + jt * 32 + li] = acc64[jt][r];
     }
 }
 
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(256) void k_gram_finish(GramParams p, int n, float*
     const size_t pidx = (size_t)I * p.NB - (size_t)I * (I - 1) / 2 + (J - I);
     const size_t off = pidx * (size_t)(MB * MB) + (size_t)(ri - I * MB) * MB + (rj - J * MB);
     double s = 0.0;
-    for (int k = 0; k < p.nsplit; ++k) s += (double)p.slabs[(size_t)k * p.npairs * (size_t)(MB * MB) + off];
+    for (int k = 0; k < p.nsplit; ++k) s += p.slabs[(size_t)k * p.npairs * (size_t)(MB * MB) + off];
     const float val = (float)(2.0 * s);
     *dst = accumulate ? (*dst + val) : val;
   }
@@ -233,7 +246,7 @@ static int gram_plan(const effq_geom* g, int has_bias, GramParams* pp) {
   if (want < 1) want = 1;
   long long max_by_work = chunks / 8;
   if (max_by_work < 1) max_by_work = 1;
-  long long max_by_mem = ((long long)1 << 30) / ((long long)p.npairs * MB * MB * 4);
+  long long max_by_mem = ((long long)1 << 30) / ((long long)p.npairs * MB * MB * 8);
   if (max_by_mem < 1) max_by_mem = 1;
   long long ns = want;
   if (ns > max_by_work) ns = max_by_work;
@@ -255,7 +268,7 @@ extern "C" {
 size_t effq_gram_ws_bytes(const effq_geom* g, int has_bias) {
   GramParams p;
   if (gram_plan(g, has_bias, &p) != EFFQ_OK) return 0;
-  return (size_t)p.nsplit * p.npairs * (size_t)(MB * MB) * sizeof(float) + 256;
+  return (size_t)p.nsplit * p.npairs * (size_t)(MB * MB) * sizeof(double) + 256;
 }
 
 int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc, const effq_geom* g, int has_bias,
@@ -264,7 +277,7 @@ int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc
   GramParams p;
   int rc = gram_plan(g, has_bias, &p);
   if (rc != EFFQ_OK) return rc;
-  const size_t need = (size_t)p.nsplit * p.npairs * (size_t)(MB * MB) * sizeof(float);
+  const size_t need = (size_t)p.nsplit * p.npairs * (size_t)(MB * MB) * sizeof(double);
   if (ws_bytes < need) {
     set_error("gram: workspace %zu < required %zu", ws_bytes, need);
     return EFFQ_ERR_WORKSPACE;
@@ -272,7 +285,7 @@ int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc
   p.x = x_ndhwc;
   p.att = att;
   p.y = y_ndhwc;
-  p.slabs = reinterpret_cast<float*>(ws);
+  p.slabs = reinterpret_cast<double*>(ws);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_gram, dim3((unsigned)p.npairs, (unsigned)p.nsplit), dim3(256), 0, st, p);
   EFFQ_LAUNCH_CHECK();

@@ -178,6 +178,7 @@ class EfficientQConvHIP(PTQConv):
         self.mask_pyramid = None
         self.layer_loss = None
         self.last_trace = None          # diagnostics of the last calibration (not in the reference)
+        self.lwq_trace = kwQ.get('lwq_trace', False)   # record the per-iteration loss (one host sync each)
 
     @staticmethod
     def _std(m: torch.Tensor) -> float:
@@ -250,7 +251,7 @@ class EfficientQConvHIP(PTQConv):
         Ainv, rho_of_inv = None, None
         guess = 16
         a_w = 1.0
-        w_iters = []
+        w_iters, hist = [], []
         for i in range(self.lwq_iter):                                     # (:99-144)
             if rho_of_inv != rho:      # A changes only with rho: 5 inverses per layer, not 200 LU solves
                 Ainv = ops.spd_inverse(A0, has_b, rho, eta, out=Ainv)
@@ -266,6 +267,8 @@ class EfficientQConvHIP(PTQConv):
             ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div)
             ops.conv_step(xq, G, bstar, geom, yn, None, sqerr=sqerr)       # unweighted MSE (quirk Q5)
             red(sqerr)
+            if self.lwq_trace:
+                hist.append(sqerr[0].item())
             ops.admm_keep_best(sqerr, best, i, G, bstar, best_G, best_b)
             if i % RHO_PERIOD == 0:
                 rho = rho * 2 if rho * 2 <= rho_m else rho_m
@@ -284,7 +287,7 @@ class EfficientQConvHIP(PTQConv):
             self.layer_loss.append(f'{self.name:45s}:{lossf}')
         self.last_trace = dict(rho_scale=rho_scale, best_iter=int(best_h[1]), best_mse=best_h[0] / numel,
                                final_mse=fin_h[0] / numel, layer_loss=lossf, act_iters=act_iters,
-                               w_iters=w_iters, alpha_w=a_w)
+                               w_iters=w_iters, alpha_w=a_w, loss_history=[h / numel for h in hist])
 
     def compute_quant_error(self, output_fp, Qw, Qact):
         """EfficientQConv.py:168-172."""

@@ -1,0 +1,124 @@
+"""Layer- and model-level parity of the HIP path on a real MI355X (-m gpu): the product's
+EfficientQConvHIP.ptq / calibrate_model against reference goldens (g5, g6) and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import effq_oracle as O
+from tests.test_host_cpu import _layer_from_gold, _tiny, T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _to_dev(conv):
+    conv.to(DEV)
+    conv.output_fp = conv.output_fp.to(DEV)
+    if conv.mask_pyramid:
+        conv.mask_pyramid = [m.to(DEV) for m in conv.mask_pyramid]
+    return conv
+
+
+@pytest.mark.parametrize("tag", ["L4", "L16", "first", "k1"])
+def test_layer_calibration_matches_reference(gold, tag):
+    """north_star bar: per-layer quantised output within 1e-3 relative MSE of the reference path;
+    quantiser indices of the calibrated weights bit-exact at 4 levels."""
+    g = gold("g5_layer_ptq.npz")
+    conv, x, (L_w, L_a, q_act) = _layer_from_gold(g, tag)
+    _to_dev(conv)
+    conv.set_quantizing()
+    with torch.no_grad():
+        out = conv(x.to(DEV))
+    want_loss = float(g[f"{tag}_layer_loss"])
+    got_loss = float(conv.layer_loss[0].split(":")[1])
+    assert abs(got_loss - want_loss) <= 1e-3 * want_loss, (got_loss, want_loss)
+    wg = T(g[f"{tag}_weight"])
+    w = conv.weight.data.cpu()
+    lv = lambda t: torch.round((t / t.abs().max() + 1) * (L_w - 1) / 2)
+    mism = (lv(w) != lv(wg)).float().mean().item()
+    if L_w == 4:
+        assert mism == 0.0
+    else:
+        assert mism <= 0.05          # 16+/256 levels: flat plateau, a few % of indices move
+    if q_act:
+        a_ref = float(g[f"{tag}_alpha_act"])
+        assert abs(conv.alpha_act.item() - a_ref) <= 1e-6 * a_ref
+    ref_out = T(g[f"{tag}_fwd_q"])
+    rel_mse = ((out.cpu() - ref_out) ** 2).mean() / (ref_out ** 2).mean()
+    assert rel_mse <= 1e-3
+    tr = conv.last_trace
+    # the best-iterate loss is what the reference selected on, to 1e-3
+    assert abs(tr["best_mse"] - float(g[f"{tag}_loss_hist"].min())) <= 1e-3 * float(g[f"{tag}_loss_hist"].min())
+
+
+def test_layer_calibration_vs_oracle_bigger_layer():
+    """A 32->32 3^3 layer (the dominant BraTS shape, reduced volume) against the CPU oracle."""
+    from efficientq_amd.qconv import EfficientQConvHIP
+    gen = torch.Generator().manual_seed(2024)
+    c, S, N = 32, 12, 2
+    conv = EfficientQConvHIP(c, c, 3, 1, 1, 1, 1, True, q_weight=True, qlvl=4, q_act=True, qlvl_act=4)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (c * 27)) ** 0.5)
+        conv.bias.copy_(torch.randn(c, generator=gen) * 0.1)
+    x_fp = torch.relu(torch.randn(N, c, S, S, S, generator=gen))
+    y = torch.nn.functional.conv3d(x_fp, conv.weight.data, conv.bias.data, 1, 1)
+    x = torch.relu(x_fp + 0.05 * torch.randn(x_fp.shape, generator=gen))
+    att = torch.randint(1, 3, (N, S, S, S), generator=gen).float()
+    want = O.calibrate_layer(x, y, conv.weight.data.clone(), conv.bias.data.clone(), 1, 1, qlvl_w=4, qlvl_act=4,
+                             q_act=True, mask_pyramid=[att])
+    conv.output_fp, conv.name, conv.layer_loss, conv.mask_pyramid = y, "big", [], [att]
+    conv.lwq_trace = True
+    _to_dev(conv)
+    conv.set_quantizing()
+    with torch.no_grad():
+        conv(x.to(DEV))
+    got_loss = float(conv.layer_loss[0].split(":")[1])
+    hist, ref_hist = np.array(conv.last_trace["loss_history"]), np.array(want.loss_history)
+    # before the discrete trajectories can separate, the per-iteration losses agree closely
+    assert np.all(np.abs(hist[:5] - ref_hist[:5]) <= 1e-4 * ref_hist[:5]), (hist[:8], ref_hist[:8])
+    # plateau value: the two runs settle on iterates whose losses agree to a fraction of a percent
+    assert abs(hist.min() - ref_hist.min()) <= 5e-3 * ref_hist.min()
+    assert abs(got_loss - want.layer_loss) <= 5e-3 * want.layer_loss
+    # NOTE: at this size the 4-level optimum is not unique: the two runs keep different iterates of the same
+    # loss plateau, so output-vs-output distance is not a parity measure here (both sit ~16% from the FP
+    # target, ~3% from each other); the quantisation error itself (layer_loss) is what must agree.
+    print(f"layer_loss hip={got_loss:.8f} oracle={want.layer_loss:.8f} best hip={hist.min():.8f} "
+          f"oracle={ref_hist.min():.8f} first-iters rel={np.abs(hist[:5] - ref_hist[:5]) / ref_hist[:5]}")
+    assert abs(conv.alpha_act.item() - np.float32(want.alpha_act)) <= 1e-6 * want.alpha_act
+    assert abs(conv.last_trace["rho_scale"] - want.rho_scale) <= 1e-6 * want.rho_scale
+
+
+@pytest.mark.parametrize("task,fname", [("brats", "g6_tiny_brats_L4.npz"), ("lits", "g6_tiny_lits_L4.npz")])
+def test_whole_calibration_matches_reference(gold, task, fname):
+    from efficientq_amd import calibrate as K
+    g = gold(fname)
+    args, model, _ = _tiny(task)
+    model.load_state_dict({k[4:]: T(g[k]) for k in g.files if k.startswith("sd0/")}, strict=False)
+    model.eval()
+    K.search_fold_and_remove_bn(model)
+    model.to(DEV)
+    S = int(g["meta"][1])
+    nmod = 1 if task == "lits" else 2
+    vols = torch.randn(2, nmod, S, S, S, generator=torch.Generator().manual_seed(int(g["vols_seed"])))
+    if task == "brats":
+        zz = torch.arange(S).float() - (S - 1) / 2
+        r = (zz[:, None, None] ** 2 + zz[None, :, None] ** 2 + zz[None, None, :] ** 2).sqrt()
+        vols = vols * (r < 0.45 * S).float()
+    K.set_name(model)
+    res = K.calibrate_model(model, vols.to(DEV), task, args.init_stride)
+    names = [l.split(":")[0].strip() for l in res["layer_loss"]]
+    assert names == g["layer_names"].tolist()
+    got = np.array([float(l.split(":")[1]) for l in res["layer_loss"]])
+    want = g["layer_loss"]
+    assert res["nums"] == g["class_nums"].tolist()
+    for i, m in enumerate(res["pyramid"]):
+        assert torch.equal(m.cpu(), T(g[f"pyr{i}"]).float())
+    sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4), slice(None, None, 4))
+    assert torch.allclose(res["output_fp"][-1][sub].cpu(), T(g["output_fp_sub"]), atol=2e-5)
+    # first layers see identical inputs: 1e-3 relative; later layers drift with the kept plateau iterate
+    assert np.all(np.abs(got[:2] - want[:2]) <= 1e-3 * want[:2]), (got, want)
+    assert np.all(np.abs(got - want) <= 8e-2 * want), (got, want)
+    assert abs(got.sum() - want.sum()) <= 4e-2 * want.sum()
+    agree = ((res["output_q"][-1] > 0) == (res["output_fp"][-1] > 0)).float().mean().item()
+    assert abs(agree - float(g["agree"])) <= 1e-2       # Dice-proxy within 1 pt on the tiny net
+    assert res["t2"] > res["t1"] > res["t0"]
