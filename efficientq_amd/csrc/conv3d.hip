@@ -11,6 +11,7 @@
 // v_mfma_f32_32x32x2_f32) take channels {0-3} and {4-7} of an 8-channel chunk, giving 4 MFMAs per
 // LDS read.  Weights are repacked once per call into [tap][c/4][c2][4] so that a wave's B operand
 // is one coalesced 16-byte load per lane straight from L2 (shared by every workgroup).
+#include <stdlib.h>
 #include "common.h"
 
 namespace effq {
@@ -37,6 +38,7 @@ struct ConvParams {
   double* partials;
   unsigned int* ticket;
   double* sqerr;
+  int debug;   // profiling ablations only (EFFQ_CONV_DEBUG): 1 = no MFMA loop, 2 = no halo staging, 3 = no epilogue loads
 };
 
 __device__ __forceinline__ float act_qd(float x, float alpha, float d) {
@@ -195,9 +197,239 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvParams p) {
   }
 }
 
+
+// ---- specialised path: 3x3x3, stride 1, 32-channel slabs ------------------------------------------
+// Same mapping as k_conv3d, plus: compile-time halo geometry (6x6x10 voxels, 36-float stride), the
+// per-tap weight block [8 chunks-of-4][32*NT][4] staged once per workgroup through a double-buffered
+// LDS ring (global -> registers at the top of a tap, registers -> LDS behind the tap's MFMAs, one
+// barrier per tap), and a fully unrolled 4-chunk body so that all LDS operand reads of a tap are in
+// flight ahead of its 16*NT MFMAs.
+constexpr int F_HD = TD + 2, F_HH = TH + 2, F_HW = TW + 2, F_NH = F_HD * F_HH * F_HW, F_CS = 36;
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
+  // Persistent form: gridDim.x workgroups (<= 2 per CU) each walk a contiguous run of spatial tiles.
+  // The global loads of stage k+1 (halo slab, and the targets of the next tile) are issued right
+  // before the 27-tap MFMA loop of stage k and land in registers underneath it, so HBM/L2 latency and
+  // the epilogue operands are off the critical path; the loss is accumulated per workgroup and only
+  // gridDim.x*gridDim.y partials take part in the deterministic grid sum.
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+  float* halo = lds;
+  float4* wbuf = reinterpret_cast<float4*>(lds + F_NH * F_CS);   // [2][8][32*NT] float4
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ch0 = blockIdx.y * 32 * NT;
+  const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per;
+  const int t_end = (t_begin + per < p.ntiles) ? t_begin + per : p.ntiles;
+  const int nstage = (t_end > t_begin) ? (t_end - t_begin) * p.nslab : 0;
+
+  constexpr int CPV = 8 * NT;                  // 16-byte cells per output voxel
+  constexpr int NCELL = 4 * NT;                // cells per thread (128 voxels x CPV / 256)
+  constexpr int NHL = (F_NH * 8 + 255) / 256;  // halo 16-byte loads per thread (12)
+  constexpr int TS = 32 * NT + 4;              // transpose row stride (floats)
+
+  struct Tile {
+    int n, od0, oh0, ow0;
+  };
+  auto decode = [&](int tile) {
+    Tile r;
+    int t = tile;
+    r.ow0 = (t % p.tiles_w) * TW;
+    t /= p.tiles_w;
+    r.oh0 = (t % p.tiles_h) * TH;
+    t /= p.tiles_h;
+    r.od0 = (t % p.tiles_d) * TD;
+    r.n = t / p.tiles_d;
+    return r;
+  };
+  auto load_halo = [&](const Tile& tl, int slab, float4(&hreg)[NHL]) {
+    const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u >> 3, c4 = u & 7;
+      const int hw = vox % F_HW;
+      const int t2 = vox / F_HW;
+      const int hh = t2 % F_HH, hd = t2 / F_HH;
+      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+      hreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u < F_NH * 8 && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && p.debug != 2)
+        hreg[k] = *reinterpret_cast<const float4*>(p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 +
+                                                   slab * 32 + c4 * 4);
+    }
+  };
+  auto load_y = [&](const Tile& tl, float4(&yv)[NCELL]) {
+#pragma unroll
+    for (int k = 0; k < NCELL; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u / CPV;
+      const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
+      yv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (od < p.OD && oh < p.OH && ow < p.OW && p.debug != 3)
+        yv[k] = *reinterpret_cast<const float4*>(p.y + ((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 +
+                                                 ch0 + (u % CPV) * 4);
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+
+  const int hv = (wid * F_HH + (li >> 3)) * F_HW + (li & 7);
+  float alpha = 1.0f;
+  if (p.act_on) alpha = *p.act_alpha;
+  const int c4q = p.c1p >> 2;
+  const int wq = tid >> 5, wj = tid & 31;      // this thread's slot of the per-tap weight block
+  const size_t wtap = (size_t)c4q * p.c2p;     // float4 stride between taps
+  const bool has_y = p.y != nullptr;
+  double l0 = 0.0, l1 = 0.0;
+
+  float4 hreg[NHL], ynext[NCELL], ycur[NCELL];
+#pragma unroll
+  for (int k = 0; k < NCELL; ++k) ycur[k] = ynext[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nstage > 0) {
+    const Tile t0 = decode(t_begin);
+    load_halo(t0, 0, hreg);
+    if (has_y) load_y(t0, ynext);
+  }
+
+  int tile = t_begin, slab = 0;
+  for (int k = 0; k < nstage; ++k) {
+    const float4* wsrc = reinterpret_cast<const float4*>(p.wp) + ((size_t)(slab * 8 + wq) * p.c2p + ch0 + wj);
+    float4 w0[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) w0[nt] = wsrc[nt * 32];
+    __syncthreads();                             // LDS (halo / ring / transpose buffer) is free
+#pragma unroll
+    for (int q = 0; q < NHL; ++q) {
+      const int u = tid + q * 256;
+      if (u < F_NH * 8) {
+        float4 v = hreg[q];
+        if (p.act_on) {
+          v.x = act_qd(v.x, alpha, p.act_d);
+          v.y = act_qd(v.y, alpha, p.act_d);
+          v.z = act_qd(v.z, alpha, p.act_d);
+          v.w = act_qd(v.w, alpha, p.act_d);
+        }
+        *reinterpret_cast<float4*>(&halo[(u >> 3) * F_CS + (u & 7) * 4]) = v;
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wbuf[wq * (32 * NT) + nt * 32 + wj] = w0[nt];
+    if (slab == 0) {
+#pragma unroll
+      for (int q = 0; q < NCELL; ++q) ycur[q] = ynext[q];
+    }
+    __syncthreads();
+
+    // prefetch of stage k+1 (next slab of this tile, or slab 0 + targets of the next tile)
+    int tile_n = tile, slab_n = slab + 1;
+    if (slab_n == p.nslab) {
+      slab_n = 0;
+      tile_n = tile + 1;
+    }
+    if (k + 1 < nstage) {
+      const Tile tn = decode(tile_n);
+      load_halo(tn, slab_n, hreg);
+      if (slab_n == 0 && has_y) load_y(tn, ynext);
+    }
+
+    const int ntap = (p.debug == 1) ? 0 : 27;
+#pragma unroll 1
+    for (int tap = 0; tap < ntap; ++tap) {
+      const int buf = tap & 1;
+      float4 wnext[NT];
+      const int tnx = (tap + 1 < 27) ? tap + 1 : tap;     // last tap re-reads itself (never written back)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wnext[nt] = wsrc[(size_t)tnx * wtap + nt * 32];
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const float* arow = halo + (hv + (kd * F_HH + kh) * F_HW + kw) * F_CS + 4 * lh;
+      const float4* brow = wbuf + buf * (8 * 32 * NT) + lh * (32 * NT) + li;
+      float4 a[4], b[4][NT];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = *reinterpret_cast<const float4*>(arow + q * 8);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[q][nt] = brow[(2 * q) * (32 * NT) + nt * 32];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q][nt].x, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q][nt].y, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q][nt].z, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q][nt].w, acc[nt], 0, 0, 0);
+      }
+      if (tap + 1 < 27) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wbuf[(buf ^ 1) * (8 * 32 * NT) + wq * (32 * NT) + nt * 32 + wj] = wnext[nt];
+      }
+      __syncthreads();
+    }
+
+    if (slab == p.nslab - 1) {
+      // ---- tile epilogue: transpose the accumulators through LDS (halo space is free after the last
+      // tap's barrier) so that every thread handles whole 16-byte (voxel, 4-channel) cells.
+      const Tile tl = decode(tile);
+      float* tb = lds;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = (p.bias != nullptr) ? p.bias[ch0 + nt * 32 + li] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          tb[(wid * 32 + i) * TS + nt * 32 + li] = acc[nt][r] + bv;
+          acc[nt][r] = 0.0f;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < NCELL; ++q) {
+        const int u = tid + q * 256;
+        const int vox = u / CPV, c4 = u % CPV;
+        const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
+        if (od < p.OD && oh < p.OH && ow < p.OW) {
+          const size_t vo = (((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow;
+          const float4 o = *reinterpret_cast<const float4*>(&tb[vox * TS + c4 * 4]);
+          if (p.out != nullptr) *reinterpret_cast<float4*>(p.out + vo * p.C2 + ch0 + c4 * 4) = o;
+          if (has_y) {
+            const float d0 = o.x - ycur[q].x, d1 = o.y - ycur[q].y, d2 = o.z - ycur[q].z, d3 = o.w - ycur[q].w;
+            const float s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3;
+            const double sq = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+            l0 += sq;
+            if (p.att != nullptr) {
+              const float av = p.att[vo];
+              l1 += ((double)(av * s0) + (double)(av * s1)) + ((double)(av * s2) + (double)(av * s3));
+            } else {
+              l1 += sq;
+            }
+          }
+        }
+      }
+    }
+    tile = tile_n;
+    slab = slab_n;
+  }
+  if (has_y) {
+    double v[2] = {l0, l1};
+    grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
+                       gridDim.x * gridDim.y);
+  }
+}
+
 struct ConvPlan {
   ConvParams p;
   int nt;
+  bool fast;
   dim3 grid;
   size_t lds_bytes;
   size_t wp_floats;
@@ -258,9 +490,24 @@ static int make_plan(const effq_geom* g, ConvPlan* pl) {
   while (nsub % nt != 0) nt >>= 1;
   // keep the chip busy on small (deep) layers: prefer more workgroups over wider waves
   while (nt > 1 && (long long)p.ntiles * (nsub / nt) < 1024) nt >>= 1;
+  // 3x3x3 / stride 1 / whole 32-channel slabs of 16-byte-aligned channel vectors: specialised kernel
+  pl->fast = (p.KD == 3 && p.KH == 3 && p.KW == 3 && p.SD == 1 && p.SH == 1 && p.SW == 1 && cslab == 32 &&
+              (p.C1 % 32) == 0 && (p.C2 % 32) == 0);
+  if (pl->fast) {
+    if (nt > 2) nt = 2;
+    pl->lds_bytes = (size_t)F_NH * F_CS * sizeof(float) + (size_t)2 * 8 * 32 * nt * sizeof(float4);
+  }
   pl->nt = nt;
   pl->grid = dim3((unsigned)p.ntiles, (unsigned)(nsub / nt), 1);
-  pl->nblk = (size_t)p.ntiles * (nsub / nt);
+  if (pl->fast) {
+    // persistent: two workgroups per CU walk contiguous runs of tiles
+    const int ny = nsub / nt;
+    int gx = (512 + ny - 1) / ny;
+    if (gx < 64) gx = 64;
+    if (gx > p.ntiles) gx = p.ntiles;
+    pl->grid = dim3((unsigned)gx, (unsigned)ny, 1);
+  }
+  pl->nblk = (size_t)pl->grid.x * pl->grid.y;
   pl->T = p.KD * p.KH * p.KW;
   pl->wp_floats = (size_t)pl->T * p.c1p * p.c2p;
   return EFFQ_OK;
@@ -313,6 +560,10 @@ int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* 
   p.act_on = act_alpha_dev != nullptr;
   p.act_alpha = act_alpha_dev;
   p.act_d = p.act_on ? (float)(1.0 / (double)(act_levels - 1)) : 1.0f;
+  {
+    const char* dbg = getenv("EFFQ_CONV_DEBUG");
+    p.debug = dbg ? atoi(dbg) : 0;
+  }
   hipStream_t st = as_stream(stream);
   if (y_fp != nullptr) EFFQ_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned int), st));
   {
@@ -329,7 +580,15 @@ int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
     hipLaunchKernelGGL(k_conv3d<NTV>, pl.grid, dim3(256), lds, st, p);                                         \
   } while (0)
-  if (pl.nt == 4)
+  if (pl.fast) {
+    if (pl.nt == 2) {
+      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_k3<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_conv3d_k3<2>, pl.grid, dim3(256), lds, st, p);
+    } else {
+      hipLaunchKernelGGL(k_conv3d_k3<1>, pl.grid, dim3(256), lds, st, p);
+    }
+  } else if (pl.nt == 4)
     EFFQ_CONV_LAUNCH(4);
   else if (pl.nt == 2)
     EFFQ_CONV_LAUNCH(2);

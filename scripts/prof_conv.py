@@ -16,7 +16,14 @@ w = (torch.randn(C, C, 3, 3, 3, generator=g) * 0.03).to(dev)
 b = torch.zeros(C, device=dev)
 geom = make_geom((N, C, S, S, S), C, 3, 1, 1)
 sq = torch.zeros(2, dtype=torch.float64, device=dev)
+ops.conv_step(x, w, b, geom, y, None, sqerr=sq)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 for _ in range(n):
     ops.conv_step(x, w, b, geom, y, None, sqerr=sq)
+e1.record()
 torch.cuda.synchronize()
-print("sqerr", sq.tolist())
+ms = e0.elapsed_time(e1) / n
+fl = 2.0 * C * C * 27 * N * S ** 3
+print(f"sqerr {sq.tolist()}  avg {ms:.4f} ms  {fl / ms / 1e9:.2f} TFLOP/s  {fl / ms / 1e9 / 157.3 * 100:.1f}% of f32 MFMA peak")
