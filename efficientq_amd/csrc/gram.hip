@@ -2,7 +2,7 @@
 // Reference: solver.py:86-111 (im2col_loop), :253-257 (ones row), :282-314 (getA0B0).
 //
 // The patch matrix is never built.  Rows of the extended operand E are
-//   [ x rows (tap-major: r = tap*C1 + c) | ones row (bias) | y rows (C2) ]
+//   [ x rows (tap-major: r = tap*C1 + c) | y rows (C2) | ones row (bias) ]
 // and one symmetric product S = sum_v att_v E(:,v) E(:,v)^T gives everything:
 //   A0 = 2*S[x|1 , x|1],  B0 = 2*S[y , x|1].
 // Work split: 128x128 macro blocks of the upper triangle of S  x  voxel splits (split-K).
@@ -31,6 +31,7 @@ struct GramParams {
   long long V;
   int nsplit;
   long long vox_per_split;
+  int fold;
   double* slabs;
 };
 
@@ -38,29 +39,60 @@ struct VoxInfo {
   int n, id0, ih0, iw0;  // input-space origin of the receptive field; n < 0 => voxel out of range
 };
 
-__device__ __forceinline__ float gram_fetch(const GramParams& p, int rkind, int kd, int kh, int kw, int c,
-                                            const VoxInfo& vi, long long v) {
-  // rkind: 0 x row, 1 ones row, 2 y row (c = y channel), 3 padding
-  if (vi.n < 0 || rkind == 3) return 0.0f;
-  if (rkind == 0) {
+// One staged cell = 4 consecutive extended rows of one voxel (16 bytes).  Extended row order:
+//   [ x rows, tap-major r = tap*C1 + c | y rows (C2) | ones row ]
+// so that with C1 % 4 == 0 and C2 % 4 == 0 every cell is either 4 channels of one tap (one 16-byte
+// load of x), 4 channels of y, or the ones/padding cell.
+struct RowGroup {
+  int kind;        // 0: x cell (kd,kh,kw,c0)   1: y cell (c0)   2: mixed, decode per row   3: padding
+  int kd, kh, kw, c0;
+  int r0;
+};
+
+__device__ __forceinline__ float gram_fetch_row(const GramParams& p, int r, const VoxInfo& vi, unsigned v) {
+  if (r < p.RX) {
+    const int tap = r / p.C1, c = r - tap * p.C1;
+    const int kw = tap % p.KW, t2 = tap / p.KW;
+    const int kh = t2 % p.KH, kd = t2 / p.KH;
     const int id = vi.id0 + kd, ih = vi.ih0 + kh, iw = vi.iw0 + kw;
     if (id < 0 || id >= p.D || ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return 0.0f;
     return p.x[((((size_t)vi.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 + c];
   }
-  if (rkind == 1) return 1.0f;
-  return p.y[(size_t)v * p.C2 + c];
+  if (r < p.RX + p.C2) return p.y[(size_t)v * p.C2 + (r - p.RX)];
+  if (p.hb && r == p.RX + p.C2) return 1.0f;
+  return 0.0f;
 }
 
-__global__ __launch_bounds__(256) void k_gram(GramParams p) {
+__device__ __forceinline__ float4 gram_fetch_cell(const GramParams& p, const RowGroup& g, const VoxInfo& vi,
+                                                  unsigned v) {
+  float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vi.n < 0 || g.kind == 3) return val;
+  if (g.kind == 0) {
+    const int id = vi.id0 + g.kd, ih = vi.ih0 + g.kh, iw = vi.iw0 + g.kw;
+    if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+      val = *reinterpret_cast<const float4*>(p.x + ((((size_t)vi.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 + g.c0);
+  } else if (g.kind == 1) {
+    val = *reinterpret_cast<const float4*>(p.y + (size_t)v * p.C2 + g.c0);
+  } else {
+    val.x = gram_fetch_row(p, g.r0 + 0, vi, v);
+    val.y = gram_fetch_row(p, g.r0 + 1, vi, v);
+    val.z = gram_fetch_row(p, g.r0 + 2, vi, v);
+    val.w = gram_fetch_row(p, g.r0 + 3, vi, v);
+  }
+  return val;
+}
+
+constexpr int GT = 512;   // threads: 8 waves = 4 row sub-tiles x 2 column halves
+
+__global__ __launch_bounds__(GT) void k_gram(GramParams p) {
   __shared__ __attribute__((aligned(16))) float panI[KC * PS];
   __shared__ __attribute__((aligned(16))) float panJ[KC * PS];
   __shared__ float att_s[KC];
-  __shared__ VoxInfo vox_s[KC];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
+  const int wi = wid & 3, wjh = wid >> 2;
 
-  // decode (I,J) of the upper triangle from the pair index
   int I = 0, rem = blockIdx.x;
   while (rem >= p.NB - I) {
     rem -= p.NB - I;
@@ -69,108 +101,135 @@ __global__ __launch_bounds__(256) void k_gram(GramParams p) {
   const int J = I + rem;
   const bool diag = (I == J);
 
-  // this thread stages one fixed row of each panel (row_local = tid % 128) for voxels tid/128, +2, ...
-  const int row_local = tid & (MB - 1);
-  const int vv0 = tid >> 7;
-  int kindI, kdI = 0, khI = 0, kwI = 0, cI = 0;
-  int kindJ, kdJ = 0, khJ = 0, kwJ = 0, cJ = 0;
-  auto decode = [&](int r, int& kind, int& kd, int& kh, int& kw, int& c) {
-    if (r < p.RX) {
-      kind = 0;
-      const int tap = r / p.C1;
-      c = r - tap * p.C1;
-      kw = tap % p.KW;
+  // staging role: cell column g (rows 4g..4g+3 of each 128-row panel), voxels vsub and vsub+16 of a chunk
+  const int g = tid & 31, vsub = tid >> 5;
+  const bool vec = (p.C1 & 3) == 0 && (p.C2 & 3) == 0;
+  auto make_group = [&](int r0) {
+    RowGroup q;
+    q.r0 = r0;
+    q.kd = q.kh = q.kw = q.c0 = 0;
+    if (r0 >= p.E) {
+      q.kind = 3;
+    } else if (vec && r0 + 3 < p.RX) {
+      q.kind = 0;
+      const int tap = r0 / p.C1;
+      q.c0 = r0 - tap * p.C1;
+      q.kw = tap % p.KW;
       const int t2 = tap / p.KW;
-      kh = t2 % p.KH;
-      kd = t2 / p.KH;
-    } else if (p.hb && r == p.RX) {
-      kind = 1;
-    } else if (r < p.E) {
-      kind = 2;
-      c = r - p.RX - p.hb;
+      q.kh = t2 % p.KH;
+      q.kd = t2 / p.KH;
+    } else if (vec && r0 >= p.RX && r0 + 3 < p.RX + p.C2) {
+      q.kind = 1;
+      q.c0 = r0 - p.RX;
     } else {
-      kind = 3;
+      q.kind = 2;
+    }
+    return q;
+  };
+  const RowGroup gI = make_group(I * MB + 4 * g), gJ = make_group(J * MB + 4 * g);
+
+  const unsigned v_begin = (unsigned)((long long)blockIdx.y * p.vox_per_split);
+  unsigned v_end = v_begin + (unsigned)p.vox_per_split;
+  if (v_end > (unsigned)p.V) v_end = (unsigned)p.V;
+
+  auto vox_info = [&](unsigned v) {
+    VoxInfo vi;
+    if (v < v_end) {
+      unsigned t = v;
+      const int ow = (int)(t % (unsigned)p.OW);
+      t /= (unsigned)p.OW;
+      const int oh = (int)(t % (unsigned)p.OH);
+      t /= (unsigned)p.OH;
+      const int od = (int)(t % (unsigned)p.OD);
+      vi.n = (int)(t / (unsigned)p.OD);
+      vi.id0 = od * p.SD - p.PD;
+      vi.ih0 = oh * p.SH - p.PH;
+      vi.iw0 = ow * p.SW - p.PW;
+    } else {
+      vi.n = -1;
+      vi.id0 = vi.ih0 = vi.iw0 = 0;
+    }
+    return vi;
+  };
+
+  float4 rI[2], rJ[2];
+  float ratt = 0.0f;
+  auto prefetch = [&](unsigned v0) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const unsigned v = v0 + vsub + 16 * ps;
+      const VoxInfo vi = vox_info(v);
+      rI[ps] = gram_fetch_cell(p, gI, vi, v);
+      if (!diag) rJ[ps] = gram_fetch_cell(p, gJ, vi, v);
+    }
+    if (tid < KC) {
+      const unsigned v = v0 + tid;
+      ratt = (v < v_end) ? ((p.att != nullptr) ? p.att[v] : 1.0f) : 0.0f;
     }
   };
-  decode(I * MB + row_local, kindI, kdI, khI, kwI, cI);
-  decode(J * MB + row_local, kindJ, kdJ, khJ, kwJ, cJ);
 
-  // fp32 MFMA accumulation runs over ONE chunk (KC voxels) only and is then folded into fp64
-  // accumulators: the normal equations are ill-conditioned (cond ~1e3-1e6, and the bias column is
-  // nearly collinear with the non-negative activations), so a 1e-7 relative error in A0 moves the
-  // ADMM losses at the 1e-3 level.  With the fold the Gram is accurate to ~1e-9 at full size.
-  double acc64[4][16];
+  // fp32 MFMA accumulation runs over `fold` chunks (KC voxels each) and is then folded into fp64
+  // accumulators: the normal equations are ill-conditioned (cond ~1e3-1e6, the bias column is nearly
+  // collinear with the non-negative activations); a 2e-7 relative error in A0 moved the ADMM losses by
+  // 1e-3.  fold = 1 for small problems, 4 when the voxel count itself averages the rounding down.
+  double acc64[2][16];
+  f32x16 acc[2];
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
+  for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc64[jt][r] = 0.0;
-
-  const long long v_begin = (long long)blockIdx.y * p.vox_per_split;
-  long long v_end = v_begin + p.vox_per_split;
-  if (v_end > p.V) v_end = p.V;
+    for (int r = 0; r < 16; ++r) {
+      acc64[jt][r] = 0.0;
+      acc[jt][r] = 0.0f;
+    }
+  const int fold = p.fold;
+  int since = 0;
   const float* pj = diag ? panI : panJ;
 
-  for (long long v0 = v_begin; v0 < v_end; v0 += KC) {
+  if (v_begin < v_end) prefetch(v_begin);
+  for (unsigned v0 = v_begin; v0 < v_end; v0 += KC) {
     __syncthreads();  // previous chunk fully consumed
-    if (tid < KC) {
-      const long long v = v0 + tid;
-      VoxInfo vi;
-      float a = 0.0f;
-      if (v < v_end) {
-        long long t = v;
-        const int ow = (int)(t % p.OW);
-        t /= p.OW;
-        const int oh = (int)(t % p.OH);
-        t /= p.OH;
-        const int od = (int)(t % p.OD);
-        vi.n = (int)(t / p.OD);
-        vi.id0 = od * p.SD - p.PD;
-        vi.ih0 = oh * p.SH - p.PH;
-        vi.iw0 = ow * p.SW - p.PW;
-        a = (p.att != nullptr) ? p.att[v] : 1.0f;
-      } else {
-        vi.n = -1;
-        vi.id0 = vi.ih0 = vi.iw0 = 0;
-      }
-      vox_s[tid] = vi;
-      att_s[tid] = a;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int vv = vv0; vv < KC; vv += 2) {
-      const VoxInfo vi = vox_s[vv];
-      panI[vv * PS + row_local] = gram_fetch(p, kindI, kdI, khI, kwI, cI, vi, v0 + vv);
-      if (!diag) panJ[vv * PS + row_local] = gram_fetch(p, kindJ, kdJ, khJ, kwJ, cJ, vi, v0 + vv);
-    }
-    __syncthreads();
-    f32x16 acc[4];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
+    for (int ps = 0; ps < 2; ++ps) {
+      const int vv = vsub + 16 * ps;
+      *reinterpret_cast<float4*>(&panI[vv * PS + 4 * g]) = rI[ps];
+      if (!diag) *reinterpret_cast<float4*>(&panJ[vv * PS + 4 * g]) = rJ[ps];
+    }
+    if (tid < KC) att_s[tid] = ratt;
+    __syncthreads();
+    if (v0 + KC < v_end) prefetch(v0 + KC);      // lands in registers under the MFMAs below
 #pragma unroll 4
     for (int s = 0; s < KC / 2; ++s) {
       const int vv = 2 * s + lh;
-      const float a = panI[vv * PS + wid * 32 + li] * att_s[vv];
+      const float a = panI[vv * PS + wi * 32 + li] * att_s[vv];
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const float b = pj[vv * PS + jt * 32 + li];
+      for (int jt = 0; jt < 2; ++jt) {
+        const float b = pj[vv * PS + (2 * wjh + jt) * 32 + li];
         acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[jt], 0, 0, 0);
       }
     }
+    if (++since == fold) {
+      since = 0;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+      for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc64[jt][r] += (double)acc[jt][r];
+        for (int r = 0; r < 16; ++r) {
+          acc64[jt][r] += (double)acc[jt][r];
+          acc[jt][r] = 0.0f;
+        }
+    }
   }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc64[jt][r] += (double)acc[jt][r];
 
   double* dst = p.slabs + ((size_t)blockIdx.y * p.npairs + blockIdx.x) * (size_t)(MB * MB);
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
+  for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      dst[(size_t)(wid * 32 + i) * MB + jt * 32 + li] = acc64[jt][r];
+      dst[(size_t)(wi * 32 + i) * MB + (2 * wjh + jt) * 32 + li] = acc64[jt][r];
     }
 }
 
@@ -186,7 +245,7 @@ __global__ __launch_bounds__(256) void k_gram_finish(GramParams p, int n, float*
       const int a = (int)(e / n), b = (int)(e % n);
       // reference row a = c*T + tap  ->  internal tap*C1 + c ; bias row -> RX
       auto to_int = [&](int q) {
-        if (p.hb && q == n - 1) return p.RX;
+        if (p.hb && q == n - 1) return p.RX + p.C2;
         const int c = q / p.T, tap = q - c * p.T;
         return tap * p.C1 + c;
       };
@@ -202,12 +261,17 @@ __global__ __launch_bounds__(256) void k_gram_finish(GramParams p, int n, float*
       const size_t f = e - nA;
       const int c2 = (int)(f / n), b = (int)(f % n);
       if (p.hb && b == n - 1)
-        ri = p.RX;
+        ri = p.RX + p.C2;
       else {
         const int c = b / p.T, tap = b - c * p.T;
         ri = tap * p.C1 + c;
       }
-      rj = p.RX + p.hb + c2;
+      rj = p.RX + c2;
+      if (ri > rj) {   // (y, ones): the ones row sits after the y rows
+        const int t = ri;
+        ri = rj;
+        rj = t;
+      }
       dst = B0 + f;
     }
     const int I = ri / MB, J = rj / MB;
@@ -256,6 +320,8 @@ static int gram_plan(const effq_geom* g, int has_bias, GramParams* pp) {
   ns = (chunks + cps - 1) / cps;
   p.nsplit = (int)ns;
   p.vox_per_split = cps * KC;
+  p.fold = (p.V >= (1ll << 20)) ? 4 : 1;
+  EFFQ_CHECK_ARG(p.V < (1ll << 31));
   return EFFQ_OK;
 }
 
@@ -287,7 +353,7 @@ int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc
   p.y = y_ndhwc;
   p.slabs = reinterpret_cast<double*>(ws);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(k_gram, dim3((unsigned)p.npairs, (unsigned)p.nsplit), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_gram, dim3((unsigned)p.npairs, (unsigned)p.nsplit), dim3(GT), 0, st, p);
   EFFQ_LAUNCH_CHECK();
   const int n = p.RX + p.hb;
   size_t tot = (size_t)n * n + (size_t)p.C2 * n;
