@@ -61,6 +61,9 @@ SIGNATURES = {
     "effq_fp_init": (_I, [_P, _P, _P]),
     "effq_fp_update": (_I, [_P, _D, _I, _P]),
     "effq_alpha_fixed_point": (_I, [_P, _SZ, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
+    "effq_fp_small_max": (_SZ, []),
+    "effq_fixed_point_small": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P]),
+    "effq_fp_check": (_I, [_P, _P, _P]),
     "effq_gram_ws_bytes": (_SZ, [_GP, _I]),
     "effq_gram_accum": (_I, [_P, _P, _P, _GP, _I, _P, _P, _I, _P, _SZ, _P]),
     "effq_spd_inverse_ws_bytes": (_SZ, [_I]),

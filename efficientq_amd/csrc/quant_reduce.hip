@@ -154,6 +154,119 @@ __global__ __launch_bounds__(TPB) void k_reduce(const float* __restrict__ x, siz
   grid_sum_finish<NS>(acc, partials, ticket, out, smem, &s_last);
 }
 
+
+// ---- fused fixed-point iteration: statistics pass whose last-arriving block also performs the scalar
+// update (layer_helper.py:55-60), so one launch = one iteration.  Used where no all-reduce sits between
+// the two (replicated weights; single-GPU activations).
+__global__ __launch_bounds__(TPB) void k_fp_iter(const float* __restrict__ x, size_t n, effq_fp_state* st, double lo,
+                                                 double hi, double d, double tol, int max_iter, double* partials,
+                                                 unsigned int* ticket) {
+  __shared__ double smem[2 * 16];
+  __shared__ int s_last;
+  if (st->done != 0) return;  // uniform across the grid
+  const double alpha = st->alpha;
+  double acc[2] = {0.0, 0.0};
+  const size_t nv = n / 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double r;
+      const double b = disc64((double)e[k], alpha, lo, hi, d, &r);
+      acc[0] += b * (double)e[k];
+      acc[1] += b * b;
+    }
+  }
+  for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double r;
+    const double b = disc64((double)x[i], alpha, lo, hi, d, &r);
+    acc[0] += b * (double)x[i];
+    acc[1] += b * b;
+  }
+  // the finishing block writes the sums into st->sums, then applies the update
+  grid_sum_finish<2>(acc, partials, ticket, st->sums, smem, &s_last);
+  if (s_last && threadIdx.x == 0) {
+    const double a_new = st->sums[0] / st->sums[1];
+    st->alpha_prev = alpha;
+    st->alpha = a_new;
+    const int it = st->iters + 1;
+    st->iters = it;
+    if (it >= max_iter)
+      st->done = 2;
+    else if (!(fabs(a_new - alpha) > tol))
+      st->done = 1;
+  }
+}
+
+// ---- whole project_by_iter in ONE launch for small tensors (weights of most layers): a single
+// 1024-thread workgroup computes mean|v|, then iterates statistics + update until convergence or the
+// cap, all on chip.  v = a + b2 (b2 may be NULL) is formed on the fly and optionally stored to v_out.
+constexpr int FPS_T = 1024;
+__global__ __launch_bounds__(FPS_T) void k_fp_small(const float* __restrict__ a, const float* __restrict__ b2,
+                                                    float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
+                                                    double hi, double d, double tol, int max_iter) {
+  __shared__ double smem[2 * 16];
+  __shared__ double s_alpha;
+  __shared__ int s_done;
+  const int tid = threadIdx.x;
+  double acc[2] = {0.0, 0.0};
+  for (size_t i = tid; i < n; i += FPS_T) {
+    const float v = (b2 != nullptr) ? (a[i] + b2[i]) : a[i];
+    if (v_out != nullptr) v_out[i] = v;
+    acc[0] += fabs((double)v);
+  }
+  block_sum<2>(acc, smem);
+  if (tid == 0) {
+    s_alpha = acc[0] / (double)n;
+    s_done = 0;
+  }
+  __syncthreads();
+  const float* src = (v_out != nullptr) ? v_out : a;   // when v_out is NULL, b2 must be NULL as well
+  double alpha = s_alpha, alpha_prev = -999.0;
+  int it = 0, done = 0;
+  while (!done) {
+    acc[0] = acc[1] = 0.0;
+    for (size_t i = tid; i < n; i += FPS_T) {
+      const double v = (double)src[i];
+      double r;
+      const double bq = disc64(v, alpha, lo, hi, d, &r);
+      acc[0] += bq * v;
+      acc[1] += bq * bq;
+    }
+    block_sum<2>(acc, smem);
+    if (tid == 0) {
+      const double a_new = acc[0] / acc[1];
+      int dn = 0;
+      if (it + 1 >= max_iter)
+        dn = 2;
+      else if (!(fabs(a_new - alpha) > tol))
+        dn = 1;
+      s_alpha = a_new;
+      s_done = dn;
+      st->sums[0] = acc[0];
+      st->sums[1] = acc[1];
+    }
+    __syncthreads();
+    alpha_prev = alpha;
+    alpha = s_alpha;
+    done = s_done;
+    ++it;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    st->alpha = alpha;
+    st->alpha_prev = alpha_prev;
+    st->iters = it;
+    st->done = done;
+  }
+}
+
+__global__ void k_check_state(const effq_fp_state* st, int32_t* err_flag) {
+  if (st->done != 1) *err_flag = (st->done == 2) ? 2 : 3;
+}
+
 __global__ void k_fp_init(effq_fp_state* st, const double* abs_sums) {
   st->alpha = abs_sums[0] / abs_sums[1];
   st->alpha_prev = -999.0;
@@ -331,14 +444,35 @@ int effq_fp_update(effq_fp_state* state_dev, double tol, int max_iter, void* str
 
 int effq_alpha_fixed_point(const float* x, size_t n, int levels, double lo, double hi, double tol, int max_iter,
                            int n_iters, effq_fp_state* state_dev, void* ws, void* stream) {
-  EFFQ_CHECK_ARG(x && state_dev && ws && n > 0 && n_iters >= 0);
-  for (int i = 0; i < n_iters; ++i) {
-    int rc = effq_alpha_stats_f64(x, &state_dev->alpha, lo, hi, levels, n, state_dev->sums, &state_dev->done, ws,
-                                  stream);
-    if (rc != EFFQ_OK) return rc;
-    rc = effq_fp_update(state_dev, tol, max_iter, stream);
-    if (rc != EFFQ_OK) return rc;
-  }
+  EFFQ_CHECK_ARG(x && state_dev && ws && n > 0 && n_iters >= 0 && levels >= 2 && hi > lo);
+  RedWs r = red_ws(ws);
+  const double d = (hi - lo) / (double)(levels - 1);
+  const int grid = stream_grid((n + 3) / 4);
+  for (int i = 0; i < n_iters; ++i)
+    hipLaunchKernelGGL(k_fp_iter, dim3(grid), dim3(TPB), 0, as_stream(stream), x, n, state_dev, lo, hi, d, tol,
+                       max_iter, r.partials, r.ticket);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+size_t effq_fp_small_max(void) { return (size_t)1 << 17; }
+
+int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                           double tol, int max_iter, effq_fp_state* state_dev, void* stream) {
+  EFFQ_CHECK_ARG(a && state_dev && n > 0 && levels >= 2 && hi > lo && max_iter > 0);
+  EFFQ_CHECK_ARG(n <= effq_fp_small_max());
+  EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
+  const double d = (hi - lo) / (double)(levels - 1);
+  hipLaunchKernelGGL(k_fp_small, dim3(1), dim3(FPS_T), 0, as_stream(stream), a, b, v_out, n, state_dev, lo, hi, d, tol,
+                     max_iter);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_fp_check(const effq_fp_state* state_dev, int32_t* err_flag_dev, void* stream) {
+  EFFQ_CHECK_ARG(state_dev && err_flag_dev);
+  hipLaunchKernelGGL(k_check_state, dim3(1), dim3(1), 0, as_stream(stream), state_dev, err_flag_dev);
+  EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }
 

@@ -174,6 +174,22 @@ class HipOps:
                 raise RuntimeWarning(f"Exceed maximum iteration ({cap}) for alpha optimization")
             batch = min(max(8, iters // 2), 256)
 
+    def weight_fixed_point(self, wstar, dual, v, levels: int, state, guess: int = 16):
+        """Projection input v = wstar + dual and its scale fixed point (EfficientQConv.py:108).
+        Small tensors: ONE launch, no host round trip (returns None).  Large ones: fused iterations in
+        batches with one 40-byte read per batch (returns the iteration count)."""
+        n = wstar.numel()
+        if n <= self.lib.effq_fp_small_max():
+            check(self.lib.effq_fixed_point_small(_ptr(wstar), _ptr(dual), _ptr(v), n, levels, -1.0, 1.0, ADMM_TOL,
+                                                  100 * levels, _ptr(state), self.stream), "effq_fixed_point_small")
+            return None
+        self.admm_presum(wstar, dual, v)
+        _, it, _ = self.fit_scale(v, levels, -1.0, 1.0, guess_iters=guess, state=state)
+        return it
+
+    def fp_check(self, state, err_flag):
+        check(self.lib.effq_fp_check(_ptr(state), _ptr(err_flag), self.stream), "effq_fp_check")
+
     # -- a5/a6 --------------------------------------------------------------------------------
     def gram(self, x_ndhwc: torch.Tensor, att: Optional[torch.Tensor], y_ndhwc: torch.Tensor, geom: Geom,
              has_bias: bool, A0: Optional[torch.Tensor] = None, B0: Optional[torch.Tensor] = None):

@@ -248,6 +248,7 @@ class EfficientQConvHIP(PTQConv):
         sqerr = torch.zeros(2, dtype=torch.float64, device=dev)
         best = torch.zeros(2, dtype=torch.float64, device=dev)
         st_w = ops.new_fp_state()
+        fp_err = torch.zeros(1, dtype=torch.int32, device=dev)
         Ainv, rho_of_inv = None, None
         guess = 16
         a_w = 1.0
@@ -257,10 +258,11 @@ class EfficientQConvHIP(PTQConv):
                 Ainv = ops.spd_inverse(A0, has_b, rho, eta, out=Ainv)
                 rho_of_inv = rho
             ops.prox_solve(B0, Ainv, W0, b0, G, dual, rho, eta, wstar, bstar)
-            ops.admm_presum(wstar, dual, v)
-            a_w, it_w, _ = ops.fit_scale(v, self.qlvl_w, -1.0, 1.0, guess_iters=guess, state=st_w)
-            guess = it_w + 2
-            w_iters.append(it_w)
+            it_w = ops.weight_fixed_point(wstar, dual, v, self.qlvl_w, st_w, guess)   # (:108) no host sync
+            ops.fp_check(st_w, fp_err)                                                # when the tensor is small
+            if it_w is not None:
+                guess = it_w + 2
+                w_iters.append(it_w)
             dual_div = 1.0
             if i % RHO_PERIOD == 0:                                        # (:129-137)
                 dual_div = 2.0 if rho * 2 <= rho_m else rho_m / rho
@@ -273,6 +275,9 @@ class EfficientQConvHIP(PTQConv):
             if i % RHO_PERIOD == 0:
                 rho = rho * 2 if rho * 2 <= rho_m else rho_m
 
+        a_w, _, _ = ops.read_fp_state(st_w)                                # one sync per layer
+        if fp_err.item() != 0:                                             # layer_helper.py:62-64
+            raise RuntimeWarning(f'Exceed maximum iteration ({100 * self.qlvl_w}) for alpha optimization')
         self.weight.data = best_G.reshape(self.weight.shape)               # (:147-158)
         if has_b:
             self.bias.data = best_b

@@ -96,10 +96,21 @@ int effq_fp_init(effq_fp_state* state_dev, const double* abs_sums_dev, void* str
  * Reads state->sums (so an all-reduce of state->sums may run between stats and update). */
 int effq_fp_update(effq_fp_state* state_dev, double tol, int max_iter, void* stream);
 
-/* Whole fixed point on the stream without host round trips: runs stats+update
- * `n_iters` times (each a no-op once done).  The caller checks state.done afterwards. */
+/* Fixed point on the stream without host round trips: runs `n_iters` fused iterations (statistics pass
+ * whose last block also applies the update; each a no-op once done).  The caller checks state.done. */
 int effq_alpha_fixed_point(const float* x, size_t n, int levels, double lo, double hi, double tol,
                            int max_iter, int n_iters, effq_fp_state* state_dev, void* ws, void* stream);
+
+/* Whole project_by_iter of a SMALL tensor (n <= effq_fp_small_max()) in one launch, no host round trip:
+ * v = a + b (b may be NULL; v is written to v_out when given, required if b != NULL), alpha0 = mean|v|,
+ * then the fixed point runs on chip until |d alpha| <= tol or max_iter.  The ADMM weight projection of
+ * most layers (EfficientQConv.py:108 -> layer_helper.py:40-70). */
+size_t effq_fp_small_max(void);
+int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                           double tol, int max_iter, effq_fp_state* state_dev, void* stream);
+/* Sticky device-side check used by stream-resident loops: *err_flag_dev = 2 (cap hit; the reference
+ * raises, layer_helper.py:62-64) or 3 (not finished) unless state.done == 1. */
+int effq_fp_check(const effq_fp_state* state_dev, int32_t* err_flag_dev, void* stream);
 
 /* ---- a5/a6: im2col + getA0B0 (solver.py:86-111, 282-314), never materialising x_col ----
  * A0 = 2*sum_v att_v xhat_v xhat_v^T, B0 = 2*sum_v att_v y_v xhat_v^T; xhat has a trailing 1

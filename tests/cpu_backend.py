@@ -65,6 +65,18 @@ class OracleOps:
         st[0] = a
         return a, n, st
 
+    def weight_fixed_point(self, wstar, dual, v, levels, state, guess=16):
+        self.admm_presum(wstar, dual, v)
+        _, it, _ = self.fit_scale(v, levels, -1.0, 1.0, state=state)
+        return it
+
+    def fp_check(self, state, err_flag):
+        pass      # fit_scale above raises on the spot, like the reference
+
+    @staticmethod
+    def read_fp_state(state):
+        return state[0].item(), 0, 1
+
     # a5/a6
     def gram(self, x_ndhwc, att, y_ndhwc, geom, has_bias, A0=None, B0=None):
         k = (geom.KD, geom.KH, geom.KW)

@@ -267,3 +267,26 @@ def test_reductions_are_run_to_run_deterministic(ops):
     assert len(vals) == 1
     ms = {tuple(ops.moments(xs).cpu().tolist()) for _ in range(5)}
     assert len(ms) == 1
+
+
+@pytest.mark.parametrize("L", [4, 16, 256])
+def test_single_launch_weight_fixed_point_matches_goldens(ops, gold, L):
+    """effq_fixed_point_small: v = w* + dual formed on the fly, whole project_by_iter in one launch."""
+    g = gold("g2_project.npz")
+    wgt = T(g["wgt"])
+    half = dev(wgt * 0.75)
+    rest = dev(wgt - wgt * 0.75)
+    v = torch.empty_like(half)
+    st = ops.new_fp_state()
+    assert ops.weight_fixed_point(half, rest, v, L, st) is None
+    alpha, iters, done = ops.read_fp_state(st)
+    vsum = (wgt * 0.75) + (wgt - wgt * 0.75)
+    fit = O.fit_scale(vsum, L, -1, 1)
+    assert torch.equal(v.cpu(), vsum)
+    assert done == 1 and iters == fit.iters and abs(alpha - fit.alpha) <= 1e-11 * fit.alpha
+    err = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    ops.fp_check(st, err)
+    assert err.item() == 0
+    # fused multi-workgroup iterations (the large-tensor path) agree with the single-launch path
+    a2, it2, _ = ops.fit_scale(v, L, -1.0, 1.0)
+    assert it2 == iters and abs(a2 - alpha) <= 1e-12 * alpha
