@@ -66,6 +66,7 @@ SIGNATURES = {
     "effq_fp_check": (_I, [_P, _P, _P]),
     "effq_gram_ws_bytes": (_SZ, [_GP, _I]),
     "effq_gram_accum": (_I, [_P, _P, _P, _GP, _I, _P, _P, _I, _P, _SZ, _P]),
+    "effq_ainv_ld": (_I, [_I]),
     "effq_spd_inverse_ws_bytes": (_SZ, [_I]),
     "effq_spd_inverse": (_I, [_P, _I, _I, _D, _D, _P, _P, _SZ, _P]),
     "effq_prox_ws_bytes": (_SZ, [_I, _I]),

@@ -13,6 +13,8 @@ namespace effq {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
 constexpr int NBK = 64;        // Gauss-Jordan block size
 constexpr int LDA_S = 66;      // LDS leading dims (doubles): conflict-free ds_read_b64 operand fetches
 constexpr int LDB_S = 80;
@@ -163,13 +165,13 @@ __global__ __launch_bounds__(256) void k_gj_step(double* __restrict__ A, int npa
 }
 
 __global__ __launch_bounds__(256) void k_a64_to_f32(const double* __restrict__ A64, int n, int npad,
-                                                    float* __restrict__ Ainv) {
-  const size_t tot = (size_t)n * n;
+                                                    float* __restrict__ Ainv, int lda) {
+  const size_t tot = (size_t)n * lda;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) {
-    const int i = (int)(e / n), j = (int)(e % n);
-    // symmetrise: the exact inverse is symmetric; average the two computed halves
-    Ainv[e] = (float)(0.5 * (A64[(size_t)i * npad + j] + A64[(size_t)j * npad + i]));
+    const int i = (int)(e / lda), j = (int)(e % lda);
+    // symmetrise: the exact inverse is symmetric; average the two computed halves.  Columns >= n are padding.
+    Ainv[e] = (j < n) ? (float)(0.5 * (A64[(size_t)i * npad + j] + A64[(size_t)j * npad + i])) : 0.0f;
   }
 }
 
@@ -197,52 +199,93 @@ __global__ __launch_bounds__(256) void k_build_b(const float* __restrict__ B0, c
   }
 }
 
-// What = Bm * Ainv (Ainv symmetric n x n).  One wave per 32x32 output tile, K = n, operands read
-// straight from L2 (Bm as 16-byte fragments, Ainv rows coalesced across lanes).
+// What = Bm * Ainv on the f32 matrix cores.  Ainv is exactly symmetric, so What[r][c] = sum_k Bm[r][k] *
+// Ainv[c][k]: BOTH operands are read along K (contiguous, 16-byte loads), staged as [row][32+4] tiles in
+// LDS (conflict-free ds_read_b128, 4 MFMAs per pair of reads) with the next K tile prefetched into
+// registers under the MFMAs of the current one.  Workgroup tile = (32*WM) x (32*WN*NTN), 4 waves.
+constexpr int PBK = 32, PLD = PBK + 4;
+
+template <int WM, int WN, int NTN>
 __global__ __launch_bounds__(256) void k_prox_gemm(const float* __restrict__ Bm, int ldb, const float* __restrict__ Ainv,
-                                                   int n, int c2, int has_bias, float* __restrict__ wstar,
-                                                   float* __restrict__ bstar, int ntile_n) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+                                                   int lda, int n, int c2, int has_bias, float* __restrict__ wstar,
+                                                   float* __restrict__ bstar) {
+  constexpr int BM = 32 * WM, BN = 32 * WN * NTN;
+  constexpr int NA = BM * 8 / 256, NB = BN * 8 / 256;   // 16-byte loads per thread per K tile
+  static_assert(WM * WN == 4 && NA >= 1 && NB >= 1, "4 waves");
+  __shared__ __attribute__((aligned(16))) float As[BM * PLD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * PLD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wtile = blockIdx.x * 4 + wid;
-  const int tn = wtile % ntile_n, tm = wtile / ntile_n;
-  if (tm * 32 >= ((c2 + 31) / 32) * 32) return;
-  f32x16 acc;
+  const int wm = wid / WN, wn = wid % WN;
+  const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+
+  f32x16 acc[NTN];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  const int col = tn * 32 + li;
-  const bool colok = col < n;
-  const float* brow = Bm + (size_t)(tm * 32 + li) * ldb + 4 * lh;
-  const int k8 = ldb / 8;  // ldb is a multiple of 8; rows k >= n of Ainv are never dereferenced
-  for (int kk = 0; kk < k8; ++kk) {
-    const float4 a = *reinterpret_cast<const float4*>(brow + kk * 8);
-    const int k0 = kk * 8 + 4 * lh;
-    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    if (colok) {
-      if (k0 + 0 < n) b0 = Ainv[(size_t)(k0 + 0) * n + col];
-      if (k0 + 1 < n) b1 = Ainv[(size_t)(k0 + 1) * n + col];
-      if (k0 + 2 < n) b2 = Ainv[(size_t)(k0 + 2) * n + col];
-      if (k0 + 3 < n) b3 = Ainv[(size_t)(k0 + 3) * n + col];
+  for (int t = 0; t < NTN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  float4 ra[NA], rb[NB];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int u = tid + q * 256, r = u >> 3, c4 = u & 7;
+      ra[q] = *reinterpret_cast<const float4*>(Bm + (size_t)(row0 + r) * ldb + k0 + c4 * 4);   // Bm is zero padded
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int u = tid + q * 256, r = u >> 3, c4 = u & 7;
+      const int col = col0 + r;
+      rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col < n) rb[q] = *reinterpret_cast<const float4*>(Ainv + (size_t)col * lda + k0 + c4 * 4);  // lda padded
+    }
+  };
+  const int nk = ldb / PBK;   // ldb is a multiple of 32
+  fetch(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int u = tid + q * 256;
+      *reinterpret_cast<float4*>(&As[(u >> 3) * PLD + (u & 7) * 4]) = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int u = tid + q * 256;
+      *reinterpret_cast<float4*>(&Bs[(u >> 3) * PLD + (u & 7) * 4]) = rb[q];
+    }
+    __syncthreads();
+    if (kt + 1 < nk) fetch((kt + 1) * PBK);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[(wm * 32 + li) * PLD + q * 8 + 4 * lh]);
+#pragma unroll
+      for (int t = 0; t < NTN; ++t) {
+        const float4 b = *reinterpret_cast<const float4*>(&Bs[((wn * NTN + t) * 32 + li) * PLD + q * 8 + 4 * lh]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+      }
+    }
   }
   const int nw = n - has_bias;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (row < c2 && colok) {
-      if (col < nw)
-        wstar[(size_t)row * nw + col] = acc[r];
-      else
-        bstar[row] = acc[r];
+  for (int t = 0; t < NTN; ++t) {
+    const int col = col0 + (wn * NTN + t) * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < c2 && col < n) {
+        if (col < nw)
+          wstar[(size_t)row * nw + col] = acc[t][r];
+        else
+          bstar[row] = acc[t][r];
+      }
     }
   }
 }
 
-static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace effq
 
@@ -255,6 +298,8 @@ size_t effq_spd_inverse_ws_bytes(int n) {
   const size_t npad = (size_t)round_up(n, NBK);
   return npad * npad * sizeof(double) + (size_t)NBK * npad * sizeof(double) + NBK * NBK * sizeof(double) + 256;
 }
+
+int effq_ainv_ld(int n) { return n > 0 ? round_up(n, 32) : 0; }
 
 int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double eta, float* Ainv, void* ws,
                      size_t ws_bytes, void* stream) {
@@ -295,9 +340,10 @@ int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double et
     EFFQ_LAUNCH_CHECK();
   }
   {
-    size_t nb = ((size_t)n * n + 255) / 256;
+    const int lda = effq_ainv_ld(n);
+    size_t nb = ((size_t)n * lda + 255) / 256;
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(k_a64_to_f32, dim3((unsigned)nb), dim3(256), 0, st, A64, n, npad, Ainv);
+    hipLaunchKernelGGL(k_a64_to_f32, dim3((unsigned)nb), dim3(256), 0, st, A64, n, npad, Ainv, lda);
     EFFQ_LAUNCH_CHECK();
   }
   return EFFQ_OK;
@@ -305,7 +351,7 @@ int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double et
 
 size_t effq_prox_ws_bytes(int c2, int n) {
   if (c2 <= 0 || n <= 0) return 0;
-  return (size_t)round_up(c2, 32) * round_up(n, 8) * sizeof(float) + 256;
+  return (size_t)round_up(c2, 128) * round_up(n, 32) * sizeof(float) + 256;
 }
 
 int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
@@ -317,7 +363,9 @@ int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const f
     set_error("prox_solve: workspace %zu < required %zu", ws_bytes, effq_prox_ws_bytes(c2, n));
     return EFFQ_ERR_WORKSPACE;
   }
-  const int c2p = round_up(c2, 32), ldb = round_up(n, 8);
+  // rows padded to the workgroup tile, K to the 32-wide K tile (zero filled by k_build_b)
+  const int c2p = (c2 > 64) ? round_up(c2, 128) : round_up(c2, 32), ldb = round_up(n, 32);
+  const int lda = effq_ainv_ld(n);
   float* Bm = reinterpret_cast<float*>(ws);
   hipStream_t st = as_stream(stream);
   {
@@ -327,10 +375,15 @@ int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const f
                        (float)rho, (float)eta, Bm, ldb, c2p);
     EFFQ_LAUNCH_CHECK();
   }
-  const int ntile_n = (n + 31) / 32, ntile_m = c2p / 32;
-  const int nwt = ntile_n * ntile_m;
-  hipLaunchKernelGGL(k_prox_gemm, dim3((nwt + 3) / 4), dim3(256), 0, st, Bm, ldb, Ainv, n, c2, has_bias ? 1 : 0, wstar,
-                     bstar, ntile_n);
+  if (c2p >= 128)
+    hipLaunchKernelGGL((k_prox_gemm<4, 1, 2>), dim3((n + 63) / 64, c2p / 128), dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2,
+                       has_bias ? 1 : 0, wstar, bstar);
+  else if (c2p == 64)
+    hipLaunchKernelGGL((k_prox_gemm<2, 2, 1>), dim3((n + 63) / 64, 1), dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2,
+                       has_bias ? 1 : 0, wstar, bstar);
+  else
+    hipLaunchKernelGGL((k_prox_gemm<1, 4, 1>), dim3((n + 127) / 128, 1), dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2,
+                       has_bias ? 1 : 0, wstar, bstar);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

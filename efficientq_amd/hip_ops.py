@@ -216,8 +216,8 @@ class HipOps:
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
         n = A0.shape[0]
         A0 = self._f32(A0)
-        if out is None:
-            out = torch.empty(n, n, dtype=torch.float32, device=self.device)
+        if out is None:     # n rows of effq_ainv_ld(n) floats (zero padded, 16-byte aligned rows)
+            out = torch.empty(n, self.lib.effq_ainv_ld(n), dtype=torch.float32, device=self.device)
         ws = self._workspace("inv", self.lib.effq_spd_inverse_ws_bytes(n))
         check(self.lib.effq_spd_inverse(_ptr(A0), n, int(has_bias), rho, eta, _ptr(out), _ptr(ws), ws.numel(),
                                         self.stream), "effq_spd_inverse")

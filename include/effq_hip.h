@@ -122,8 +122,10 @@ int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc
                     void* stream);
 
 /* ---- a7: getAB + solve (solver.py:316-345) --------------------------------------
- * Ainv = (A0 + rho*I' + eta*I)^-1 in fp64 (I' has 0 on the bias diagonal), stored fp32 [n x n].
+ * Ainv = (A0 + rho*I' + eta*I)^-1 in fp64 (I' has 0 on the bias diagonal), stored fp32 as n rows of
+ * effq_ainv_ld(n) floats (row padding is zero; exactly symmetric).
  * The reference refactorises per iteration; A only changes with rho (5 values per layer). */
+int effq_ainv_ld(int n);
 size_t effq_spd_inverse_ws_bytes(int n);
 int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double eta, float* Ainv,
                      void* ws, size_t ws_bytes, void* stream);

@@ -174,7 +174,9 @@ def test_spd_inverse_and_prox(ops, n, c2):
     d = torch.full((n,), rho + eta, dtype=torch.float64)
     d[-1] = eta
     A += torch.diag(d)
-    Ainv = ops.spd_inverse(dev(A0), True, rho, eta).cpu()
+    Ainv_pad = ops.spd_inverse(dev(A0), True, rho, eta)
+    Ainv = Ainv_pad.cpu()[:, :n]
+    assert Ainv_pad.shape[1] % 32 == 0 and Ainv_pad[:, n:].abs().sum().item() == 0
     want = torch.linalg.inv(A)
     assert (Ainv.double() - want).abs().max() <= 2e-7 * want.abs().max() + 1e-12
     B0 = torch.randn(c2, n, generator=gen) * 10
@@ -184,7 +186,7 @@ def test_spd_inverse_and_prox(ops, n, c2):
     dual = torch.randn(c2, n - 1, generator=gen) * 0.1
     wstar = torch.empty(c2, n - 1, device="cuda:0")
     bstar = torch.empty(c2, device="cuda:0")
-    ops.prox_solve(dev(B0), dev(Ainv), dev(W0), dev(b0), dev(G), dev(dual), rho, eta, wstar, bstar)
+    ops.prox_solve(dev(B0), Ainv_pad, dev(W0), dev(b0), dev(G), dev(dual), rho, eta, wstar, bstar)
     Bm = B0.double() + eta * torch.cat([W0, b0[:, None]], 1).double()
     Bm[:, :-1] += rho * (G - dual).double()
     wantW = torch.linalg.solve(A, Bm.T).T
