@@ -67,33 +67,87 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ G
   }
 }
 
+// Generic geometry (any kernel / stride / channel count), persistent: each workgroup walks a contiguous
+// run of tiles; the halo slab of stage k+1 and the targets of the next tile are fetched into registers
+// right before the MFMA loop of stage k, so the memory phases of these (mostly bandwidth-bound) layers
+// overlap the arithmetic.  Weights come straight from L2 (one 16-byte load per lane per 4 MFMAs).
+constexpr int G_MAXH = 12;   // halo 16-byte loads per thread per slab (plan guarantees nhalo*cslab/4 <= 3072)
+
 template <int NT>
-__global__ __launch_bounds__(256) void k_conv3d(ConvParams p) {
+__global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ double red_smem[2 * 16];
   __shared__ int s_last;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-
-  // XCD-aware, bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
-  // contiguous run of spatial tiles so neighbouring halos hit the same L2.
-  int tile;
-  {
-    const unsigned bid = blockIdx.x, nwg = (unsigned)p.ntiles;
-    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, idx = bid >> 3;
-    tile = (int)(xcd * q + (xcd < r ? xcd : r) + idx);
-  }
-  int t = tile;
-  const int tw_i = t % p.tiles_w;
-  t /= p.tiles_w;
-  const int th_i = t % p.tiles_h;
-  t /= p.tiles_h;
-  const int td_i = t % p.tiles_d;
-  const int n = t / p.tiles_d;
-  const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
-  const int id0 = od0 * p.SD - p.PD, ih0 = oh0 * p.SH - p.PH, iw0 = ow0 * p.SW - p.PW;
   const int ch0 = blockIdx.y * 32 * NT;
+  const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per;
+  const int t_end = (t_begin + per < p.ntiles) ? t_begin + per : p.ntiles;
+  const int nstage = (t_end > t_begin) ? (t_end - t_begin) * p.nslab : 0;
+
+  struct Tile {
+    int n, od0, oh0, ow0;
+  };
+  auto decode = [&](int tile) {
+    Tile r;
+    int t = tile;
+    r.ow0 = (t % p.tiles_w) * TW;
+    t /= p.tiles_w;
+    r.oh0 = (t % p.tiles_h) * TH;
+    t /= p.tiles_h;
+    r.od0 = (t % p.tiles_d) * TD;
+    r.n = t / p.tiles_d;
+    return r;
+  };
+  const int HH = p.HH, HW = p.HW, CS = p.CS;
+  const int upv = p.cslab >> 2;
+  const int nh4 = p.nhalo * upv;
+  const bool vec_ok = (p.C1 & 3) == 0;
+  auto load_halo = [&](const Tile& tl, int slab, float4(&hreg)[G_MAXH]) {
+    const int id0 = tl.od0 * p.SD - p.PD, ih0 = tl.oh0 * p.SH - p.PH, iw0 = tl.ow0 * p.SW - p.PW;
+#pragma unroll
+    for (int k = 0; k < G_MAXH; ++k) {
+      const int u = tid + k * 256;
+      hreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u < nh4) {
+        const int vox = u / upv, c4 = u - vox * upv;
+        const int hw = vox % HW;
+        const int t2 = vox / HW;
+        const int hh = t2 % HH, hd = t2 / HH;
+        const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+        const int c = slab * p.cslab + c4 * 4;
+        if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && c < p.C1) {
+          const float* src = p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 + c;
+          if (vec_ok) {
+            hreg[k] = *reinterpret_cast<const float4*>(src);
+          } else {
+            hreg[k].x = src[0];
+            if (c + 1 < p.C1) hreg[k].y = src[1];
+            if (c + 2 < p.C1) hreg[k].z = src[2];
+            if (c + 3 < p.C1) hreg[k].w = src[3];
+          }
+        }
+      }
+    }
+  };
+  // targets in accumulator layout: lane (li,lh), register r <-> voxel (r&3)+8*(r>>2)+4*lh of d-plane wid
+  auto load_y = [&](const Tile& tl, float(&yv)[NT][16]) {
+    const int od = tl.od0 + wid;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = ch0 + nt * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int oh = tl.oh0 + (i >> 3), ow = tl.ow0 + (i & 7);
+        yv[nt][r] = 0.0f;
+        if (ch < p.C2 && od < p.OD && oh < p.OH && ow < p.OW)
+          yv[nt][r] = p.y[((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 + ch];
+      }
+    }
+  };
 
   f32x16 acc[NT];
 #pragma unroll
@@ -101,43 +155,60 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 
-  const int HH = p.HH, HW = p.HW, CS = p.CS;
   const int hv = ((wid * p.SD) * HH + (li >> 3) * p.SH) * HW + (li & 7) * p.SW;
-  const int upv = p.cslab >> 2;
-  const bool vec_ok = (p.C1 & 3) == 0;
   float alpha = 1.0f;
   if (p.act_on) alpha = *p.act_alpha;
+  const bool has_y = p.y != nullptr;
+  double l0 = 0.0, l1 = 0.0;
 
-  for (int s = 0; s < p.nslab; ++s) {
-    __syncthreads();
-    for (int u = tid; u < p.nhalo * upv; u += 256) {
-      const int vox = u / upv, c4 = u - vox * upv;
-      const int hw = vox % HW;
-      const int t2 = vox / HW;
-      const int hh = t2 % HH, hd = t2 / HH;
-      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-      const int c = s * p.cslab + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && c < p.C1) {
-        const float* src = p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 + c;
-        if (vec_ok) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          v.x = src[0];
-          if (c + 1 < p.C1) v.y = src[1];
-          if (c + 2 < p.C1) v.z = src[2];
-          if (c + 3 < p.C1) v.w = src[3];
-        }
+  float4 hreg[G_MAXH];
+  float ynext[NT][16], ycur[NT][16];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ycur[nt][r] = ynext[nt][r] = 0.0f;
+  if (nstage > 0) {
+    const Tile t0 = decode(t_begin);
+    load_halo(t0, 0, hreg);
+    if (has_y) load_y(t0, ynext);
+  }
+
+  int tile = t_begin, slab = 0;
+  for (int k = 0; k < nstage; ++k) {
+    __syncthreads();                             // LDS free
+#pragma unroll
+    for (int q = 0; q < G_MAXH; ++q) {
+      const int u = tid + q * 256;
+      if (u < nh4) {
+        float4 v = hreg[q];
         if (p.act_on) {
           v.x = act_qd(v.x, alpha, p.act_d);
           v.y = act_qd(v.y, alpha, p.act_d);
           v.z = act_qd(v.z, alpha, p.act_d);
           v.w = act_qd(v.w, alpha, p.act_d);
         }
+        const int vox = u / upv, c4 = u - vox * upv;
+        *reinterpret_cast<float4*>(&lds[vox * CS + c4 * 4]) = v;
       }
-      *reinterpret_cast<float4*>(&lds[vox * CS + c4 * 4]) = v;
+    }
+    if (slab == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ycur[nt][r] = ynext[nt][r];
     }
     __syncthreads();
+
+    int tile_n = tile, slab_n = slab + 1;
+    if (slab_n == p.nslab) {
+      slab_n = 0;
+      tile_n = tile + 1;
+    }
+    if (k + 1 < nstage) {
+      const Tile tn = decode(tile_n);
+      load_halo(tn, slab_n, hreg);
+      if (slab_n == 0 && has_y) load_y(tn, ynext);
+    }
 
     const int nq = p.cslab >> 3;
     for (int kd = 0; kd < p.KD; ++kd)
@@ -146,7 +217,7 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvParams p) {
           const int tap = (kd * p.KH + kh) * p.KW + kw;
           const float* arow = lds + (hv + (kd * HH + kh) * HW + kw) * CS + 4 * lh;
           const float* wrow =
-              p.wp + ((size_t)(tap * (p.c1p >> 2) + ((s * p.cslab) >> 2) + lh) * p.c2p + ch0 + li) * 4;
+              p.wp + ((size_t)(tap * (p.c1p >> 2) + ((slab * p.cslab) >> 2) + lh) * p.c2p + ch0 + li) * 4;
           for (int q = 0; q < nq; ++q) {
             const float4 a = *reinterpret_cast<const float4*>(arow + q * 8);
             float4 b[NT];
@@ -163,40 +234,43 @@ __global__ __launch_bounds__(256) void k_conv3d(ConvParams p) {
             for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nt].w, acc[nt], 0, 0, 0);
           }
         }
-  }
 
-  // ---- epilogue: bias, optional store, fused squared error --------------------------------
-  double l0 = 0.0, l1 = 0.0;
-  const int od = od0 + wid;
+    if (slab == p.nslab - 1) {
+      const Tile tl = decode(tile);
+      const int od = tl.od0 + wid;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int ch = ch0 + nt * 32 + li;
-    const bool chok = ch < p.C2;
-    const float bv = (p.bias != nullptr && chok) ? p.bias[ch] : 0.0f;
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ch = ch0 + nt * 32 + li;
+        const bool chok = ch < p.C2;
+        const float bv = (p.bias != nullptr && chok) ? p.bias[ch] : 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int oh = oh0 + (i >> 3), ow = ow0 + (i & 7);
-      if (chok && od < p.OD && oh < p.OH && ow < p.OW) {
-        const size_t vo = (((size_t)n * p.OD + od) * p.OH + oh) * p.OW + ow;
-        const float o = acc[nt][r] + bv;
-        if (p.out != nullptr) p.out[vo * p.C2 + ch] = o;
-        if (p.y != nullptr) {
-          const float dlt = o - p.y[vo * p.C2 + ch];
-          const float sq = dlt * dlt;
-          l0 += (double)sq;
-          l1 += (p.att != nullptr) ? (double)(p.att[vo] * sq) : (double)sq;
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int oh = tl.oh0 + (i >> 3), ow = tl.ow0 + (i & 7);
+          if (chok && od < p.OD && oh < p.OH && ow < p.OW) {
+            const size_t vo = (((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow;
+            const float o = acc[nt][r] + bv;
+            if (p.out != nullptr) p.out[vo * p.C2 + ch] = o;
+            if (has_y) {
+              const float dlt = o - ycur[nt][r];
+              const float sq = dlt * dlt;
+              l0 += (double)sq;
+              l1 += (p.att != nullptr) ? (double)(p.att[vo] * sq) : (double)sq;
+            }
+          }
+          acc[nt][r] = 0.0f;
         }
       }
     }
+    tile = tile_n;
+    slab = slab_n;
   }
-  if (p.y != nullptr) {
+  if (has_y) {
     double v[2] = {l0, l1};
     grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
                        gridDim.x * gridDim.y);
   }
 }
-
 
 // ---- specialised path: 3x3x3, stride 1, 32-channel slabs ------------------------------------------
 // Same mapping as k_conv3d, plus: compile-time halo geometry (6x6x10 voxels, 36-float stride), the
@@ -466,6 +540,7 @@ static int make_plan(const effq_geom* g, ConvPlan* pl) {
       const int c = cands[i];
       if (c > p.c1p || p.c1p % c != 0) continue;
       const size_t bytes = (size_t)p.nhalo * (c + 4) * sizeof(float);
+      if ((size_t)p.nhalo * (c / 4) > (size_t)G_MAXH * 256) continue;   // register-staged halo loads per thread
       if (bytes <= (pass == 0 ? (size_t)64 * 1024 : (size_t)150 * 1024)) {
         cslab = c;
         break;
@@ -493,14 +568,14 @@ static int make_plan(const effq_geom* g, ConvPlan* pl) {
   // 3x3x3 / stride 1 / whole 32-channel slabs of 16-byte-aligned channel vectors: specialised kernel
   pl->fast = (p.KD == 3 && p.KH == 3 && p.KW == 3 && p.SD == 1 && p.SH == 1 && p.SW == 1 && cslab == 32 &&
               (p.C1 % 32) == 0 && (p.C2 % 32) == 0);
+  if (nt > 2) nt = 2;      // register budget of the persistent kernels (prefetch registers + accumulators)
   if (pl->fast) {
-    if (nt > 2) nt = 2;
     pl->lds_bytes = (size_t)F_NH * F_CS * sizeof(float) + (size_t)2 * 8 * 32 * nt * sizeof(float4);
   }
   pl->nt = nt;
   pl->grid = dim3((unsigned)p.ntiles, (unsigned)(nsub / nt), 1);
-  if (pl->fast) {
-    // persistent: two workgroups per CU walk contiguous runs of tiles
+  {
+    // persistent: about two workgroups per CU walk contiguous runs of tiles
     const int ny = nsub / nt;
     int gx = (512 + ny - 1) / ny;
     if (gx < 64) gx = 64;
@@ -588,9 +663,7 @@ int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* 
     } else {
       hipLaunchKernelGGL(k_conv3d_k3<1>, pl.grid, dim3(256), lds, st, p);
     }
-  } else if (pl.nt == 4)
-    EFFQ_CONV_LAUNCH(4);
-  else if (pl.nt == 2)
+  } else if (pl.nt == 2)
     EFFQ_CONV_LAUNCH(2);
   else
     EFFQ_CONV_LAUNCH(1);
