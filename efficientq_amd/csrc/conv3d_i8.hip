@@ -1,0 +1,291 @@
+// conv3d_calib_step_i8: the "int-simulated" fake-quant forward of one ADMM iteration, exact.
+// Reference: EfficientQConv.py:118-122 (conv3d(Qactivation, G, b*) + mse_loss, 200x per layer).
+//
+// With quantised activations x = alpha_a * k/(La-1) (k = level id >= 0) and projected weights
+// G = alpha_w * j'/(Lw-1) (j' = 2*level - (Lw-1)), the conv is  s * sum k*j'  with small integers, so it
+// runs on the i8 matrix cores with exact int32 accumulation (v_mfma_i32_32x32x32_i8: K = 32 channels
+// per instruction, 32x the f32 MFMA rate) and one fp32 scale + bias in the epilogue.  The kernel is
+// then HBM-bound: per output voxel it streams C2*4 bytes of target and C1 bytes of level ids.
+//
+// Mapping: persistent workgroups (4 waves) walk contiguous runs of 4x4x8 output tiles; wave w owns
+// d-plane w (32 voxels) x 32 output channels.  The wave's B operands -- all 27 taps x C1/32 channel
+// groups of its 32 output channels -- live in REGISTERS for the whole kernel (27*CG*4 VGPRs), the
+// level-id halo tile (6x6x10 voxels x C1 bytes) is staged through LDS with a 16-byte pad per voxel,
+// and the next tile's halo + targets are prefetched into registers under the current tile's MFMAs.
+#include "common.h"
+
+namespace effq {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int ITD = 4, ITH = 4, ITW = 8;
+constexpr int I_HD = ITD + 2, I_HH = ITH + 2, I_HW = ITW + 2, I_NH = I_HD * I_HH * I_HW;   // 360 voxels
+constexpr int I_TS = 36;   // transpose row stride (floats)
+
+struct ConvI8Params {
+  const int8_t* x;
+  const int8_t* wq;
+  const float* bias;
+  const float* y;
+  const float* act_alpha;
+  const effq_fp_state* wstate;
+  double inv_levels;
+  int N, C1, C2, c2p, D, H, W, OD, OH, OW, PD, PH, PW;
+  int tiles_d, tiles_h, tiles_w, ntiles;
+  double* partials;
+  unsigned int* ticket;
+  double* sqerr;
+};
+
+__global__ __launch_bounds__(256) void k_pack_weight_i8(const int8_t* __restrict__ Gq, int8_t* __restrict__ wq, int C1,
+                                                        int C2, int T, int c2p) {
+  const size_t total = (size_t)T * c2p * C1;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int c = (int)(e % C1);
+    size_t r = e / C1;
+    const int j = (int)(r % c2p);
+    const int tap = (int)(r / c2p);
+    wq[e] = (j < C2) ? Gq[((size_t)j * C1 + c) * T + tap] : (int8_t)0;
+  }
+}
+
+template <int CG>
+__global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Params p) {
+  constexpr int VS = 32 * CG + 16;                         // bytes per halo voxel in LDS
+  constexpr int NHL = (I_NH * 2 * CG + 255) / 256;         // halo 16-byte loads per thread
+  __shared__ __attribute__((aligned(16))) int8_t halo[I_NH * VS];
+  __shared__ __attribute__((aligned(16))) float tb[128 * I_TS];
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ch0 = blockIdx.y * 32;
+  const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per;
+  const int t_end = (t_begin + per < p.ntiles) ? t_begin + per : p.ntiles;
+
+  // B operands of this wave's 32 output channels: lane (j=li, k-half lh) holds 16 channels per (tap, group)
+  v4i breg[27][CG];
+  {
+    const int8_t* wrow = p.wq + ((size_t)(ch0 + li) * p.C1 + 16 * lh);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+      for (int g = 0; g < CG; ++g)
+        breg[tap][g] = *reinterpret_cast<const v4i*>(wrow + (size_t)tap * p.c2p * p.C1 + 32 * g);
+  }
+  const float scale = (float)((double)(*p.act_alpha) * (double)(float)p.wstate->alpha * p.inv_levels);
+  const float bv = (p.bias != nullptr) ? p.bias[ch0 + li] : 0.0f;
+
+  struct Tile {
+    int n, od0, oh0, ow0;
+  };
+  auto decode = [&](int tile) {
+    Tile r;
+    int t = tile;
+    r.ow0 = (t % p.tiles_w) * ITW;
+    t /= p.tiles_w;
+    r.oh0 = (t % p.tiles_h) * ITH;
+    t /= p.tiles_h;
+    r.od0 = (t % p.tiles_d) * ITD;
+    r.n = t / p.tiles_d;
+    return r;
+  };
+  auto load_halo = [&](const Tile& tl, v4i(&hreg)[NHL]) {
+    const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u / (2 * CG), part = u % (2 * CG);
+      const int hw = vox % I_HW;
+      const int t2 = vox / I_HW;
+      const int hh = t2 % I_HH, hd = t2 / I_HH;
+      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+      hreg[k] = v4i{0, 0, 0, 0};                          // level id 0 == activation value 0 == zero padding
+      if (u < I_NH * 2 * CG && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+        hreg[k] = *reinterpret_cast<const v4i*>(p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 +
+                                                part * 16);
+    }
+  };
+  auto load_y = [&](const Tile& tl, float4(&yv)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u >> 3;
+      const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
+      yv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (od < p.OD && oh < p.OH && ow < p.OW)
+        yv[k] = *reinterpret_cast<const float4*>(p.y + ((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 +
+                                                 ch0 + (u & 7) * 4);
+    }
+  };
+
+  const int hv = (wid * I_HH + (li >> 3)) * I_HW + (li & 7);
+  double l0 = 0.0;
+  v4i hreg[NHL];
+  float4 ynext[4], ycur[4];
+  if (t_begin < t_end) {
+    const Tile t0 = decode(t_begin);
+    load_halo(t0, hreg);
+    load_y(t0, ynext);
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();                                       // halo free (previous tile's MFMAs done)
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      if (u < I_NH * 2 * CG) *reinterpret_cast<v4i*>(&halo[(u / (2 * CG)) * VS + (u % (2 * CG)) * 16]) = hreg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ycur[k] = ynext[k];
+    __syncthreads();
+    if (tile + 1 < t_end) {
+      const Tile tn = decode(tile + 1);
+      load_halo(tn, hreg);
+      load_y(tn, ynext);
+    }
+    v16i acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const int8_t* arow = halo + (hv + (kd * I_HH + kh) * I_HW + kw) * VS + 16 * lh;
+#pragma unroll
+      for (int g = 0; g < CG; ++g) {
+        const v4i a = *reinterpret_cast<const v4i*>(arow + 32 * g);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, breg[tap][g], acc, 0, 0, 0);
+      }
+    }
+    // epilogue: scale + bias, transpose through LDS, compare whole 16-byte cells with the prefetched targets
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      tb[(wid * 32 + i) * I_TS + li] = (float)acc[r] * scale + bv;
+    }
+    __syncthreads();
+    const Tile tl = decode(tile);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u >> 3, c4 = u & 7;
+      const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
+      if (od < p.OD && oh < p.OH && ow < p.OW) {
+        const float4 o = *reinterpret_cast<const float4*>(&tb[vox * I_TS + c4 * 4]);
+        const float d0 = o.x - ycur[k].x, d1 = o.y - ycur[k].y, d2 = o.z - ycur[k].z, d3 = o.w - ycur[k].w;
+        l0 += ((double)(d0 * d0) + (double)(d1 * d1)) + ((double)(d2 * d2) + (double)(d3 * d3));
+      }
+    }
+  }
+  double v[2] = {l0, l0};
+  grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
+                     gridDim.x * gridDim.y);
+}
+
+struct I8Plan {
+  ConvI8Params p;
+  dim3 grid;
+  size_t nblk, wq_bytes;
+};
+
+static int i8_plan(const effq_geom* g, I8Plan* pl) {
+  EFFQ_CHECK_ARG(g != nullptr);
+  EFFQ_CHECK_ARG(g->KD == 3 && g->KH == 3 && g->KW == 3 && g->SD == 1 && g->SH == 1 && g->SW == 1);
+  EFFQ_CHECK_ARG(g->C1 == 32 || g->C1 == 64);
+  EFFQ_CHECK_ARG(g->C2 > 0 && (g->C2 % 32) == 0);
+  EFFQ_CHECK_ARG(g->N > 0 && g->D > 0 && g->H > 0 && g->W > 0 && g->PD >= 0 && g->PH >= 0 && g->PW >= 0);
+  ConvI8Params& p = pl->p;
+  memset(&p, 0, sizeof(p));
+  p.N = g->N; p.C1 = g->C1; p.C2 = g->C2; p.c2p = g->C2; p.D = g->D; p.H = g->H; p.W = g->W;
+  p.PD = g->PD; p.PH = g->PH; p.PW = g->PW;
+  p.OD = g->D + 2 * g->PD - 2; p.OH = g->H + 2 * g->PH - 2; p.OW = g->W + 2 * g->PW - 2;
+  EFFQ_CHECK_ARG(p.OD > 0 && p.OH > 0 && p.OW > 0);
+  p.tiles_d = (p.OD + ITD - 1) / ITD;
+  p.tiles_h = (p.OH + ITH - 1) / ITH;
+  p.tiles_w = (p.OW + ITW - 1) / ITW;
+  const long long nt = (long long)p.N * p.tiles_d * p.tiles_h * p.tiles_w;
+  EFFQ_CHECK_ARG(nt < (1ll << 30));
+  p.ntiles = (int)nt;
+  const int ny = p.C2 / 32;
+  const int wg_per_cu = (g->C1 == 32) ? 2 : 1;
+  int gx = (256 * wg_per_cu + ny - 1) / ny;
+  if (gx < 32) gx = 32;
+  if (gx > p.ntiles) gx = p.ntiles;
+  pl->grid = dim3((unsigned)gx, (unsigned)ny, 1);
+  pl->nblk = (size_t)gx * ny;
+  pl->wq_bytes = (size_t)27 * p.c2p * p.C1;
+  return EFFQ_OK;
+}
+
+}  // namespace effq
+
+using namespace effq;
+
+extern "C" {
+
+int effq_conv_i8_supported(const effq_geom* g, int act_levels, int w_levels) {
+  if (g == nullptr) return 0;
+  if (!(g->KD == 3 && g->KH == 3 && g->KW == 3 && g->SD == 1 && g->SH == 1 && g->SW == 1)) return 0;
+  if (!(g->C1 == 32 || g->C1 == 64) || (g->C2 % 32) != 0) return 0;
+  if (act_levels < 2 || act_levels > 128 || w_levels < 2 || w_levels > 128) return 0;
+  // int32 accumulator range: 27*C1 products of at most (La-1)*(Lw-1)
+  if ((double)27 * g->C1 * (act_levels - 1) * (w_levels - 1) >= 2147483647.0) return 0;
+  return 1;
+}
+
+size_t effq_conv_i8_ws_bytes(const effq_geom* g) {
+  I8Plan pl;
+  if (i8_plan(g, &pl) != EFFQ_OK) return 0;
+  return 256 + pl.nblk * 2 * sizeof(double) + pl.wq_bytes + 256;
+}
+
+int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const float* bias, const float* y_fp,
+                         const effq_geom* g, const float* act_alpha_dev, int act_levels,
+                         const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, void* ws, size_t ws_bytes,
+                         void* stream) {
+  EFFQ_CHECK_ARG(xidx_ndhwc && Gq && y_fp && g && act_alpha_dev && w_state_dev && sqerr_out && ws);
+  EFFQ_CHECK_ARG(effq_conv_i8_supported(g, act_levels, w_levels));
+  I8Plan pl;
+  int rc = i8_plan(g, &pl);
+  if (rc != EFFQ_OK) return rc;
+  const size_t need = 256 + pl.nblk * 2 * sizeof(double) + pl.wq_bytes + 256;
+  if (ws_bytes < need) {
+    set_error("conv_i8: workspace %zu < required %zu", ws_bytes, need);
+    return EFFQ_ERR_WORKSPACE;
+  }
+  char* base = reinterpret_cast<char*>(ws);
+  ConvI8Params& p = pl.p;
+  p.ticket = reinterpret_cast<unsigned int*>(base);
+  p.partials = reinterpret_cast<double*>(base + 256);
+  int8_t* wq = reinterpret_cast<int8_t*>(base + 256 + pl.nblk * 2 * sizeof(double));
+  wq = reinterpret_cast<int8_t*>((reinterpret_cast<uintptr_t>(wq) + 15) & ~(uintptr_t)15);
+  p.x = reinterpret_cast<const int8_t*>(xidx_ndhwc);
+  p.wq = wq;
+  p.bias = bias;
+  p.y = y_fp;
+  p.act_alpha = act_alpha_dev;
+  p.wstate = w_state_dev;
+  p.inv_levels = 1.0 / ((double)(act_levels - 1) * (double)(w_levels - 1));
+  p.sqerr = sqerr_out;
+  hipStream_t st = as_stream(stream);
+  EFFQ_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned int), st));
+  {
+    size_t nb = (pl.wq_bytes + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_pack_weight_i8, dim3((unsigned)nb), dim3(256), 0, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
+    EFFQ_LAUNCH_CHECK();
+  }
+  if (p.C1 == 32)
+    hipLaunchKernelGGL(k_conv3d_i8<1>, pl.grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(k_conv3d_i8<2>, pl.grid, dim3(256), 0, st, p);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+}  // extern "C"

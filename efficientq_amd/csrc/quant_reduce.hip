@@ -299,7 +299,7 @@ __global__ __launch_bounds__(TPB) void k_presum(const float* __restrict__ a, con
 __global__ __launch_bounds__(TPB) void k_project_dual(const float* __restrict__ v, const float* __restrict__ wstar,
                                                       const effq_fp_state* __restrict__ st, double d,
                                                       float* __restrict__ G, float* __restrict__ dual,
-                                                      float dual_div, size_t n) {
+                                                      float dual_div, int8_t* __restrict__ Gq, int lm1, size_t n) {
   const double alpha = st->alpha;
   const float alpha32 = (float)alpha;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -308,6 +308,7 @@ __global__ __launch_bounds__(TPB) void k_project_dual(const float* __restrict__ 
     float b = (float)disc64((double)v[i], alpha, -1.0, 1.0, d, &r);
     float g = alpha32 * b;
     G[i] = g;
+    if (Gq != nullptr) Gq[i] = (int8_t)(2 * (int)r - lm1);   // signed level numerator j' = 2*level - (L-1)
     float du = (wstar[i] - g) + dual[i];        // EfficientQConv.py:111
     if (dual_div != 1.0f) du = du / dual_div;   // "dual /= 2" or "dual /= rho_m/rho" (:131-136)
     dual[i] = du;
@@ -485,12 +486,13 @@ int effq_admm_presum(const float* wstar, const float* dual, float* v, size_t n, 
 }
 
 int effq_admm_project_dual(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
-                           float* dual, float dual_div, size_t n, void* stream) {
+                           float* dual, float dual_div, int8_t* Gq_out, size_t n, void* stream) {
   EFFQ_CHECK_ARG(v && wstar && state_dev && G && dual && levels >= 2 && dual_div > 0.0f);
+  EFFQ_CHECK_ARG(Gq_out == nullptr || levels <= 128);
   if (n == 0) return EFFQ_OK;
   const double d = 2.0 / (double)(levels - 1);
   hipLaunchKernelGGL(k_project_dual, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
-                     G, dual, dual_div, n);
+                     G, dual, dual_div, Gq_out, levels - 1, n);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

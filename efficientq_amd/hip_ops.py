@@ -235,9 +235,26 @@ class HipOps:
         check(self.lib.effq_admm_presum(_ptr(wstar), _ptr(dual), _ptr(v), wstar.numel(), self.stream),
               "effq_admm_presum")
 
-    def admm_project_dual(self, v, wstar, state, levels: int, G, dual, dual_div: float):
+    def admm_project_dual(self, v, wstar, state, levels: int, G, dual, dual_div: float, Gq=None):
         check(self.lib.effq_admm_project_dual(_ptr(v), _ptr(wstar), _ptr(state), levels, _ptr(G), _ptr(dual),
-                                              float(dual_div), v.numel(), self.stream), "effq_admm_project_dual")
+                                              float(dual_div), _ptr(Gq), v.numel(), self.stream),
+              "effq_admm_project_dual")
+
+    def conv_i8_supported(self, geom: Geom, act_levels: int, w_levels: int) -> bool:
+        return bool(self.lib.effq_conv_i8_supported(C.byref(geom), int(act_levels), int(w_levels)))
+
+    def conv_step_i8(self, xidx: torch.Tensor, Gq: torch.Tensor, bias, geom: Geom, y_ndhwc: torch.Tensor,
+                     act_alpha: torch.Tensor, act_levels: int, w_state: torch.Tensor, w_levels: int, sqerr):
+        """Exact-integer loss evaluation (conv3d_calib_step_i8)."""
+        if xidx.dtype != torch.uint8 or Gq.dtype != torch.int8:
+            raise _lib.EffqError("conv_step_i8 wants uint8 level ids and int8 weight numerators")
+        _check_shapes(geom, xidx, Gq, bias, y_ndhwc)
+        al = self._f32(act_alpha.reshape(1))
+        ws = self._workspace("conv_i8", self.lib.effq_conv_i8_ws_bytes(C.byref(geom)))
+        check(self.lib.conv3d_calib_step_i8(_ptr(xidx), _ptr(Gq), _ptr(bias), _ptr(self._f32(y_ndhwc)), C.byref(geom),
+                                            _ptr(al), int(act_levels), _ptr(w_state), int(w_levels), _ptr(sqerr),
+                                            _ptr(ws), ws.numel(), self.stream), "conv3d_calib_step_i8")
+        return sqerr
 
     def admm_keep_best(self, sqerr, best, it: int, G, b, best_G, best_b):
         check(self.lib.effq_admm_keep_best(_ptr(sqerr), _ptr(best), it, _ptr(G), _ptr(b), _ptr(best_G), _ptr(best_b),

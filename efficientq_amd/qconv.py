@@ -23,6 +23,8 @@ from .hip_ops import from_ndhwc, make_geom, to_ndhwc
 
 # ADMM constants are constructor constants in the reference (EfficientQConv.py:23-26)
 LWQ_ITER, LWQ_RHO, LWQ_RHO_MAX, LWQ_ETA, RHO_PERIOD = 200, 10.0, 1000.0, 1.0, 50
+import os as _os
+EXACT_INT_DEFAULT = _os.environ.get("EFFQ_EXACT_INT", "1") != "0"
 
 
 def get_ops(device):
@@ -179,6 +181,8 @@ class EfficientQConvHIP(PTQConv):
         self.layer_loss = None
         self.last_trace = None          # diagnostics of the last calibration (not in the reference)
         self.lwq_trace = kwQ.get('lwq_trace', False)   # record the per-iteration loss (one host sync each)
+        # evaluate the per-iteration losses on the i8 matrix cores (exact int32 accumulation) where supported
+        self.lwq_exact_int = kwQ.get('lwq_exact_int', EXACT_INT_DEFAULT)
 
     @staticmethod
     def _std(m: torch.Tensor) -> float:
@@ -218,6 +222,10 @@ class EfficientQConvHIP(PTQConv):
             rho_scale *= ma[0].item() / ma[2].item()
 
         act_iters = 0
+        xidx = None
+        # exact-integer evaluation of the 200 per-iteration losses (north_star's "int-simulated" forward)
+        use_i8 = bool(self.q_act and not self._act_inited and self.lwq_exact_int and
+                      getattr(ops, "conv_i8_supported", lambda *a: False)(geom, self.qlvl_act, self.qlvl_w))
         if self.q_act:                                                     # (:64-72)
             if self._act_inited:
                 xq = to_ndhwc(self._quantize_act(x))
@@ -225,7 +233,7 @@ class EfficientQConvHIP(PTQConv):
                 a_act, act_iters, st = ops.fit_scale(xn, self.qlvl_act, 0.0, 1.0, reducer=red or None,
                                                      guess_iters=12 * self.qlvl_act)
                 self.alpha_act.data = torch.tensor(a_act, dtype=x.dtype, device=dev)
-                xq, _, _ = ops.quant_dequant_f64path(xn, st, self.qlvl_act, 0.0, 1.0)
+                xq, _, xidx = ops.quant_dequant_f64path(xn, st, self.qlvl_act, 0.0, 1.0, want_idx=use_i8)
         else:
             xq = xn
 
@@ -248,6 +256,7 @@ class EfficientQConvHIP(PTQConv):
         sqerr = torch.zeros(2, dtype=torch.float64, device=dev)
         best = torch.zeros(2, dtype=torch.float64, device=dev)
         st_w = ops.new_fp_state()
+        Gq = torch.empty(W0.shape, dtype=torch.int8, device=dev) if use_i8 else None
         fp_err = torch.zeros(1, dtype=torch.int32, device=dev)
         Ainv, rho_of_inv = None, None
         guess = 16
@@ -266,8 +275,13 @@ class EfficientQConvHIP(PTQConv):
             dual_div = 1.0
             if i % RHO_PERIOD == 0:                                        # (:129-137)
                 dual_div = 2.0 if rho * 2 <= rho_m else rho_m / rho
-            ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div)
-            ops.conv_step(xq, G, bstar, geom, yn, None, sqerr=sqerr)       # unweighted MSE (quirk Q5)
+            if use_i8:
+                ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div, Gq)
+                ops.conv_step_i8(xidx, Gq, bstar, geom, yn, self.alpha_act.data, self.qlvl_act, st_w, self.qlvl_w,
+                                 sqerr)
+            else:
+                ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div)
+                ops.conv_step(xq, G, bstar, geom, yn, None, sqerr=sqerr)   # unweighted MSE (quirk Q5)
             red(sqerr)
             if self.lwq_trace:
                 hist.append(sqerr[0].item())
@@ -292,7 +306,8 @@ class EfficientQConvHIP(PTQConv):
             self.layer_loss.append(f'{self.name:45s}:{lossf}')
         self.last_trace = dict(rho_scale=rho_scale, best_iter=int(best_h[1]), best_mse=best_h[0] / numel,
                                final_mse=fin_h[0] / numel, layer_loss=lossf, act_iters=act_iters,
-                               w_iters=w_iters, alpha_w=a_w, loss_history=[h / numel for h in hist])
+                               w_iters=w_iters, alpha_w=a_w, loss_history=[h / numel for h in hist],
+                               exact_int=use_i8)
 
     def compute_quant_error(self, output_fp, Qw, Qact):
         """EfficientQConv.py:168-172."""

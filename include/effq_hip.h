@@ -144,7 +144,9 @@ int effq_admm_presum(const float* wstar, const float* dual, float* v, size_t n, 
 /* G = f32(alpha)*b with b=f32(discretize(f64(v)/alpha,-1,1)); dual = (wstar - G + dual) / dual_div.
  * dual_div is 1, or 2 / (rho_max/rho) on the rho-schedule iterations (i % 50 == 0).  alpha from state_dev. */
 int effq_admm_project_dual(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels,
-                           float* G, float* dual, float dual_div, size_t n, void* stream);
+                           float* G, float* dual, float dual_div, int8_t* Gq_out, size_t n, void* stream);
+/* Gq_out (optional, levels <= 128): signed level numerators j' = 2*level-(L-1), so that G = alpha_w*j'/(L-1);
+ * the operand of the exact-integer conv below. */
 /* Best-iterate bookkeeping on the device: if (iter==0 || loss<best_loss) copy G,b into best_G,best_b.
  * loss_dev = {sum sq err (double)}; best_dev = {best loss (double), best iter (as double)}. */
 int effq_admm_keep_best(const double* sqerr_dev, double* best_dev, int iter, const float* G, const float* b,
@@ -162,6 +164,20 @@ size_t effq_conv_ws_bytes(const effq_geom* g);
 int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* bias, const float* y_fp,
                             const float* att, const effq_geom* g, const float* act_alpha_dev, int act_levels,
                             double* sqerr_out, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- exact-integer ("int-simulated") form of the per-iteration loss evaluation -------------------
+ * Same quantity as conv3d_quant_calib_step(xq, G, bias, y_fp, NULL, ...)'s sqerr_out[0], for quantised
+ * activations and projected weights: x = alpha_a*k/(La-1) with level ids k (uint8, NDHWC) and
+ * G = alpha_w*j'/(Lw-1) with Gq = j' (int8, reference weight layout).  The contraction runs on the i8
+ * matrix cores with exact int32 accumulation; out = f32(alpha_a)*f32(alpha_w)/((La-1)(Lw-1)) * acc + bias.
+ * Supported: 3x3x3, stride 1, C1 in {32,64}, C2 % 32 == 0, levels <= 128 (query effq_conv_i8_supported).
+ * alpha_a: device float; alpha_w: w_state_dev->alpha.  sqerr_out[0] = sqerr_out[1] = sum (out-y)^2. */
+int effq_conv_i8_supported(const effq_geom* g, int act_levels, int w_levels);
+size_t effq_conv_i8_ws_bytes(const effq_geom* g);
+int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const float* bias, const float* y_fp,
+                         const effq_geom* g, const float* act_alpha_dev, int act_levels,
+                         const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, void* ws,
+                         size_t ws_bytes, void* stream);
 
 /* ---- f3 (next row): Adam step for tune_activation_range (ptqer.py:238-272) ---- */
 int effq_adam_step(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,

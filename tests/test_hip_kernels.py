@@ -292,3 +292,51 @@ def test_single_launch_weight_fixed_point_matches_goldens(ops, gold, L):
     # fused multi-workgroup iterations (the large-tensor path) agree with the single-launch path
     a2, it2, _ = ops.fit_scale(v, L, -1.0, 1.0)
     assert it2 == iters and abs(a2 - alpha) <= 1e-12 * alpha
+
+
+@pytest.mark.parametrize("c1,c2,La,Lw,sp", [(32, 32, 4, 4, (8, 8, 16)), (32, 64, 16, 16, (9, 7, 11)),
+                                             (64, 64, 4, 4, (8, 8, 8)), (64, 32, 16, 4, (5, 6, 9)),
+                                             (32, 32, 128, 128, (4, 4, 8))])
+def test_exact_int_conv_step_equals_fp32_path(ops, c1, c2, La, Lw, sp):
+    """conv3d_calib_step_i8 (i8 MFMA, exact int32 accumulation) against conv3d_quant_calib_step on the
+    SAME quantised operands: identical loss up to the fp32 path's own rounding (<= 2e-6 relative)."""
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(c1 + 7 * c2 + La)
+    N = 2
+    x = torch.relu(torch.randn(N, *sp, c1, generator=gen))                    # NDHWC
+    geom = make_geom((N, c1, *sp), c2, 3, 1, 1)
+    assert ops.conv_i8_supported(geom, La, Lw)
+    a_act, _, st_a = ops.fit_scale(dev(x), La, 0.0, 1.0)
+    xq, _, xidx = ops.quant_dequant_f64path(dev(x), st_a, La, 0.0, 1.0, want_idx=True)
+    alpha_act = torch.tensor(a_act, dtype=torch.float32, device="cuda:0")
+    wst = dev(torch.randn(c2, c1, 3, 3, 3, generator=gen) * 0.05)
+    dual = torch.zeros_like(wst)
+    v = torch.empty_like(wst)
+    st_w = ops.new_fp_state()
+    ops.weight_fixed_point(wst, dual, v, Lw, st_w)
+    if wst.numel() > ops.lib.effq_fp_small_max():
+        pass
+    G = torch.empty_like(wst)
+    Gq = torch.empty(wst.shape, dtype=torch.int8, device="cuda:0")
+    ops.admm_project_dual(v, wst, st_w, Lw, G, dual, 1.0, Gq)
+    a_w = ops.read_fp_state(st_w)[0]
+    # Gq really is the signed numerator of G
+    assert torch.equal(G.cpu(), np.float32(a_w) * (Gq.cpu().float() / (Lw - 1)).double().float()) or \
+        torch.allclose(G.cpu(), np.float32(a_w) * Gq.cpu().float() / (Lw - 1), rtol=2e-7, atol=0)
+    b = dev(torch.randn(c2, generator=gen) * 0.1)
+    y = dev(torch.randn(N, *sp, c2, generator=gen))
+    _, sq32 = ops.conv_step(xq, G, b, geom, y, None)
+    sq8 = torch.zeros(2, dtype=torch.float64, device="cuda:0")
+    ops.conv_step_i8(xidx, Gq, b, geom, y, alpha_act, La, st_w, Lw, sq8)
+    s32, s8 = sq32.cpu().tolist(), sq8.cpu().tolist()
+    assert abs(s8[0] - s32[0]) <= 2e-6 * s32[0], (s8, s32)
+    assert s8[1] == s8[0]
+    # fp64 ground truth of the same integer model
+    out = torch.nn.functional.conv3d(xidx.cpu().permute(0, 4, 1, 2, 3).double(), Gq.cpu().double(), None, 1, 1)
+    s = float(np.float32(a_act)) * float(np.float32(a_w)) / ((La - 1) * (Lw - 1))
+    ref = ((out * s + b.cpu().double().view(1, -1, 1, 1, 1) - y.cpu().permute(0, 4, 1, 2, 3).double()) ** 2).sum().item()
+    assert abs(s8[0] - ref) <= 1e-6 * ref
+    # deterministic
+    sq8b = torch.zeros(2, dtype=torch.float64, device="cuda:0")
+    ops.conv_step_i8(xidx, Gq, b, geom, y, alpha_act, La, st_w, Lw, sq8b)
+    assert sq8b.cpu().tolist() == s8

@@ -122,3 +122,31 @@ def test_whole_calibration_matches_reference(gold, task, fname):
     agree = ((res["output_q"][-1] > 0) == (res["output_fp"][-1] > 0)).float().mean().item()
     assert abs(agree - float(g["agree"])) <= 1e-2       # Dice-proxy within 1 pt on the tiny net
     assert res["t2"] > res["t1"] > res["t0"]
+
+
+def test_exact_int_and_fp32_loss_paths_agree_on_a_layer():
+    """Same layer calibrated with the per-iteration losses on the i8 matrix cores (exact) and on the f32
+    matrix cores: the early iteration losses agree to fp32 rounding, the result to the plateau tolerance."""
+    from efficientq_amd.qconv import EfficientQConvHIP
+    res = {}
+    for exact in (True, False):
+        gen = torch.Generator().manual_seed(99)
+        c, S, N = 32, 12, 2
+        conv = EfficientQConvHIP(c, c, 3, 1, 1, 1, 1, True, q_weight=True, qlvl=4, q_act=True, qlvl_act=4,
+                                 lwq_exact_int=exact, lwq_trace=True)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (c * 27)) ** 0.5)
+            conv.bias.copy_(torch.randn(c, generator=gen) * 0.1)
+        x_fp = torch.relu(torch.randn(N, c, S, S, S, generator=gen))
+        y = torch.nn.functional.conv3d(x_fp, conv.weight.data, conv.bias.data, 1, 1)
+        x = torch.relu(x_fp + 0.05 * torch.randn(x_fp.shape, generator=gen))
+        conv.output_fp, conv.name, conv.layer_loss = y, "l", []
+        _to_dev(conv)
+        conv.set_quantizing()
+        with torch.no_grad():
+            conv(x.to(DEV))
+        assert conv.last_trace["exact_int"] == exact
+        res[exact] = (np.array(conv.last_trace["loss_history"]), float(conv.layer_loss[0].split(":")[1]))
+    hi, hf = res[True][0], res[False][0]
+    assert np.all(np.abs(hi[:5] - hf[:5]) <= 2e-6 * hf[:5]), (hi[:5], hf[:5])
+    assert abs(res[True][1] - res[False][1]) <= 5e-3 * res[False][1]
