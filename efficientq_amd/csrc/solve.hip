@@ -37,34 +37,50 @@ __global__ __launch_bounds__(256) void k_build_a64(const float* __restrict__ A0,
   }
 }
 
-// Step 1: Dinv = inv(A[kb:kb+64, kb:kb+64]) by unblocked in-place Gauss-Jordan in LDS.
+// Step 1: Dinv = inv(A[kb:kb+64, kb:kb+64]) by unblocked in-place Gauss-Jordan (SPD: no pivoting).
+// Lane = row, wave w = columns 16w..16w+15, the 16 values of a row live in registers.  Per pivot p the
+// multiplier column and 1/pivot go through a parity-double-buffered LDS vector (ONE barrier per
+// pivot), the pivot row is broadcast inside each wave with v_readlane.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void k_gj_diag(const double* __restrict__ A, int npad, int kb,
                                                  double* __restrict__ Dinv) {
-  __shared__ double Ds[NBK][NBK + 1];
-  const int tid = threadIdx.x;
-  const int i = tid >> 2, j0 = (tid & 3) * 16;
-  for (int j = 0; j < 16; ++j) Ds[i][j0 + j] = A[(size_t)(kb + i) * npad + kb + j0 + j];
-  __syncthreads();
+  __shared__ double fcol[2][NBK + 1];   // [parity][row] multipliers, [NBK] = 1/pivot
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double reg[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) reg[j] = A[(size_t)(kb + lane) * npad + kb + wid * 16 + j];
+#pragma unroll 1
   for (int p = 0; p < NBK; ++p) {
-    const double piv = 1.0 / Ds[p][p];
-    const double f = Ds[i][p];
-    double rowp[16];
+    const int par = p & 1, wp = p >> 4, jp = p & 15;
+    if (wid == wp) {
+      double cp = reg[0];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) rowp[j] = Ds[p][j0 + j] * piv;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int jj = j0 + j;
-      double v;
-      if (i == p)
-        v = (jj == p) ? piv : rowp[j];
-      else
-        v = (jj == p) ? (-f * piv) : (Ds[i][jj] - f * rowp[j]);
-      Ds[i][jj] = v;
+      for (int j = 1; j < 16; ++j) cp = (jp == j) ? reg[j] : cp;
+      fcol[par][lane] = cp;
+      if (lane == p) fcol[par][NBK] = 1.0 / cp;
     }
     __syncthreads();
+    const double piv = fcol[par][NBK];
+    const double f = fcol[par][lane];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double rp = readlane_f64(reg[j], p) * piv;      // scaled pivot-row entry of this column
+      const bool colp = (wid == wp) && (jp == j);
+      double v;
+      if (lane == p)
+        v = colp ? piv : rp;
+      else
+        v = colp ? (-f * piv) : (reg[j] - f * rp);
+      reg[j] = v;
+    }
   }
-  for (int j = 0; j < 16; ++j) Dinv[i * NBK + j0 + j] = Ds[i][j0 + j];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) Dinv[lane * NBK + wid * 16 + j] = reg[j];
 }
 
 // 64x64x64 fp64 tile product on the matrix cores: acc += As(64x64) * Bs(64x64), one 32x32 quadrant per wave.
@@ -162,6 +178,59 @@ __global__ __launch_bounds__(256) void k_gj_step(double* __restrict__ A, int npa
           A[(size_t)(jb * NBK + row) * npad + kb + col] = -acc[mi][ni][r];
         }
       }
+}
+
+
+// Trailing update  A[ib, jb] -= A[ib, kb] * R[:, jb]  for a 64-row block ib and a strip of CT column
+// blocks.  The (negated) A[ib,kb] tile is staged once in LDS; the accumulators are INITIALISED with the
+// C tile (row = lk+4r, col = lr: 128-byte row segments), the R operand streams from L2 in MFMA B layout
+// (16 consecutive doubles per k row), and the result is stored back: one read + one write of the matrix
+// per elimination step, no separate read-modify-write pass.
+constexpr int GJ_CT = 4;
+__global__ __launch_bounds__(256) void k_gj_trail(double* __restrict__ A, int npad, int kb, const double* __restrict__ R) {
+  __shared__ __attribute__((aligned(16))) double As[NBK * LDA_S];
+  const int kblk = kb / NBK, nblk = npad / NBK;
+  const int ib = blockIdx.y;
+  if (ib == kblk) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int e = tid; e < NBK * NBK; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    As[r * LDA_S + c] = -A[(size_t)(ib * NBK + r) * npad + kb + c];
+  }
+  __syncthreads();
+  for (int t = 0; t < GJ_CT; ++t) {
+    const int jb = blockIdx.x * GJ_CT + t;
+    if (jb >= nblk || jb == kblk) continue;
+    double* Cb = A + (size_t)(ib * NBK + wr * 32) * npad + (size_t)jb * NBK + wc * 32;
+    const double* Rb = R + (size_t)jb * NBK + wc * 32;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = Cb[(size_t)(mi * 16 + lk + 4 * r) * npad + ni * 16 + lr];
+#pragma unroll 4
+    for (int ks = 0; ks < NBK / 4; ++ks) {
+      double a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = As[(wr * 32 + mi * 16 + lr) * LDA_S + ks * 4 + lk];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) b[ni] = Rb[(size_t)(ks * 4 + lk) * npad + ni * 16 + lr];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cb[(size_t)(mi * 16 + lk + 4 * r) * npad + ni * 16 + lr] = acc[mi][ni][r];
+  }
 }
 
 __global__ __launch_bounds__(256) void k_a64_to_f32(const double* __restrict__ A64, int n, int npad,
@@ -334,7 +403,7 @@ int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double et
     hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(256), 0, st, A64, npad, kb, Dinv);
     if (nblk > 1) {
       hipLaunchKernelGGL(k_gj_step<0>, dim3(nblk, 1), dim3(256), lds, st, A64, npad, kb, Dinv, R);
-      hipLaunchKernelGGL(k_gj_step<1>, dim3(nblk, nblk), dim3(256), lds, st, A64, npad, kb, Dinv, R);
+      hipLaunchKernelGGL(k_gj_trail, dim3((nblk + GJ_CT - 1) / GJ_CT, nblk), dim3(256), 0, st, A64, npad, kb, R);
     }
     hipLaunchKernelGGL(k_gj_step<2>, dim3(nblk, 1), dim3(256), lds, st, A64, npad, kb, Dinv, R);
     EFFQ_LAUNCH_CHECK();
