@@ -48,42 +48,84 @@ def build_model(levels, device):
     return args, model
 
 
-class ConvTimer:
-    """HIP-event pairs around the launches of the dominant conv shape inside the timed steps."""
+PEAK_F64_MFMA_TFLOPS = 78.6       # MI355X fp64 matrix peak (vendor)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+class OpTimer:
+    """HIP-event pairs (on the launch stream) around every call of the heavy library ops inside the timed
+    steps, aggregated per (op, shape).  The op class with the largest total is the dominant kernel; its
+    roofline uses the ALGORITHMIC work of one launch over the average duration."""
 
     def __init__(self):
-        self.pairs = []
-        self.flops_per_launch = None
+        self.rec = {}
 
-    def wrap(self, ops):
-        inner = ops.conv_step
-        timer = self
+    def _wrap(self, ops, name, keyfn):
+        inner = getattr(ops, name)
+        rec = self.rec
 
-        def conv_step(x, w, b, geom, y=None, att=None, **kw):
-            dom = (geom.C1 == DOMINANT["c1"] and geom.C2 == DOMINANT["c2"] and geom.KD == 3 and y is not None
-                   and geom.D * geom.H * geom.W == DOMINANT["vox"] and att is None)
-            if not dom:
-                return inner(x, w, b, geom, y, att, **kw)
+        def call(*a, **kw):
+            key = keyfn(*a, **kw)
+            if key is None:
+                return inner(*a, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = inner(x, w, b, geom, y, att, **kw)
+            r = inner(*a, **kw)
             e1.record()
-            timer.pairs.append((e0, e1))
-            timer.flops_per_launch = 2.0 * geom.C2 * geom.C1 * 27 * geom.N * geom.D * geom.H * geom.W
+            rec.setdefault((name,) + key, []).append((e0, e1))
             return r
-        ops.conv_step = conv_step
-        return lambda: setattr(ops, "conv_step", inner)
+        setattr(ops, name, call)
+        return lambda: setattr(ops, name, inner)
+
+    def wrap(self, ops):
+        def gkey(g):
+            return (g.N, g.C1, g.C2, g.D, g.H, g.W, g.KD, g.SD)
+        undo = [
+            self._wrap(ops, "conv_step", lambda x, w, b, geom, y=None, att=None, **kw: gkey(geom)),
+            self._wrap(ops, "conv_step_i8", lambda xi, gq, b, geom, *a, **kw: gkey(geom)),
+            self._wrap(ops, "gram", lambda x, att, y, geom, hb, *a, **kw: gkey(geom)),
+            self._wrap(ops, "spd_inverse", lambda A0, *a, **kw: (int(A0.shape[0]),)),
+            self._wrap(ops, "prox_solve", lambda B0, *a, **kw: (int(B0.shape[0]), int(B0.shape[1]))),
+        ]
+        return lambda: [u() for u in undo]
+
+    @staticmethod
+    def _work(key):
+        op = key[0]
+        if op in ("conv_step", "conv_step_i8", "gram"):
+            N, c1, c2, D, H, W, k, s = key[1:]
+            od, oh, ow = (D + 2 * (k // 2) - k) // s + 1, (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+            V, Vin = N * od * oh * ow, N * D * H * W
+            if op == "conv_step":
+                return ("mfma", 2.0 * c2 * c1 * k ** 3 * V, "f32 MFMA", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
+                        f"k_conv3d* ({c1}->{c2}, {k}^3/s{s}, {N}x{od}x{oh}x{ow} voxels, f32 MFMA)")
+            if op == "conv_step_i8":
+                return ("hbm", 4.0 * c2 * V + 1.0 * c1 * Vin, "HBM", PEAK_HBM_GBS, "GB/s",
+                        f"k_conv3d_i8 ({c1}->{c2}, 3^3, {N}x{od}x{oh}x{ow} voxels: 4*c2 B of target + c1 B of level "
+                        f"ids per voxel, i8 MFMA exact)")
+            n = c1 * k ** 3 + 1
+            return ("mfma", 2.0 * n * n * V + 2.0 * c2 * n * V, "f32 MFMA", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
+                    f"k_gram (n={n}, {V} voxels; 2n^2V+2c2nV flop, upper triangle computed)")
+        if op == "spd_inverse":
+            n = key[1]
+            return ("mfma", 2.0 * n ** 3, "f64 MFMA", PEAK_F64_MFMA_TFLOPS, "TFLOP/s", f"k_gj_* (n={n}, 2n^3 fp64 flop)")
+        c2, n = key[1:]
+        return ("mfma", 2.0 * c2 * n * n, "f32 MFMA", PEAK_F32_MFMA_TFLOPS, "TFLOP/s", f"k_prox_gemm (c2={c2}, n={n})")
 
     def summary(self):
-        if not self.pairs:
-            return None
-        ms = [a.elapsed_time(b) for a, b in self.pairs]
-        avg = sum(ms) / len(ms)
-        ach = self.flops_per_launch / (avg * 1e-3) / 1e12
-        return dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
-                    kernel="k_conv3d<1> (32->32, 3x3x3, 64^3 x %d vol)" % (self.flops_per_launch / (2 * 32 * 32 * 27 * 64 ** 3)),
-                    launches=len(ms), avg_ms=round(avg, 4), flops_per_launch=self.flops_per_launch)
+        rows = []
+        for key, pairs in self.rec.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            bound, work, pname, peak, unit, label = self._work(key)
+            avg = sum(ms) / len(ms)
+            ach = work / (avg * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+            rows.append(dict(kernel=label, bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
+                             frac=round(ach / peak, 4), traffic=None, launches=len(ms), avg_ms=round(avg, 4),
+                             total_ms=round(sum(ms), 1), work_per_launch=work))
+        rows.sort(key=lambda r: -r["total_ms"])
+        if not rows:
+            return None, []
+        return rows[0], rows[1:6]
 
 
 def cpu_baseline(levels):
@@ -129,8 +171,12 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--f32-only", action="store_true",
+                    help="evaluate every per-iteration loss on the f32 matrix cores (no exact-integer path)")
     a = ap.parse_args()
 
+    if a.f32_only:
+        os.environ["EFFQ_EXACT_INT"] = "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -153,7 +199,7 @@ def main():
     log(f"[rank {rank}] {a.vols} synthetic volumes 4x{a.size}^3 in HBM ({time.time() - t:.1f}s)")
 
     ops = get_ops(device)
-    timer = ConvTimer()
+    timer = OpTimer()
 
     def one_step():
         model.load_state_dict(pristine, strict=True)
@@ -183,18 +229,23 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     total_vols = a.vols * world * a.steps
-    roof = timer.summary()
+    roof, others = timer.summary()
+    from efficientq_amd import qconv as _Q
+    exact = bool(_Q.EXACT_INT_DEFAULT)
     out = {
         "metric": "ptq_calibration_throughput", "value": round(total_vols / dt, 5), "unit": "calib-vols/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
         "wall_clock_s_per_calibration": round(dt / a.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i8xi8->i32 (exact) for the per-iteration loss convs of 32/64-channel 3^3 layers, f32/f64 elsewhere"
+                 if exact else "f32", "data": "synthetic",
         "config": {"workload": f"BraTS 3D-UNet fp32->{a.levels}-level PTQ (qlvl_w={a.levels} qlvl_a={a.levels}, "
                                f"q_first=q_last=256,-1), 22 quantised convs, 200 ADMM its/layer, "
                                f"{a.vols} synthetic 4x{a.size}^3 volumes per GPU (BASELINE.json configs[1])",
                    "vols_per_gpu": a.vols, "volume": f"4x{a.size}^3", "parallelism": f"dp{world}",
                    "fp_pass_s": round(res["t1"] - res["t0"], 3), "ptq_pass_s": round(res["t2"] - res["t1"], 3)},
         "roofline": roof,
+        "other_kernels": others,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("[rank 0] timing the CPU baseline sample ...")

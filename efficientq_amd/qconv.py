@@ -43,7 +43,14 @@ class SumReducer:
 
     def __call__(self, t: torch.Tensor) -> torch.Tensor:
         if self.on:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                # rehearsal mode (several ranks on ONE GPU, where RCCL refuses duplicate devices):
+                # stage through the host; the product backend is "nccl" (= RCCL over xGMI)
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
     def __bool__(self):
