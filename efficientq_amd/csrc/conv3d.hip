@@ -210,30 +210,54 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
       if (slab_n == 0 && has_y) load_y(tn, ynext);
     }
 
-    const int nq = p.cslab >> 3;
-    for (int kd = 0; kd < p.KD; ++kd)
-      for (int kh = 0; kh < p.KH; ++kh)
-        for (int kw = 0; kw < p.KW; ++kw) {
-          const int tap = (kd * p.KH + kh) * p.KW + kw;
-          const float* arow = lds + (hv + (kd * HH + kh) * HW + kw) * CS + 4 * lh;
-          const float* wrow =
-              p.wp + ((size_t)(tap * (p.c1p >> 2) + ((slab * p.cslab) >> 2) + lh) * p.c2p + ch0 + li) * 4;
-          for (int q = 0; q < nq; ++q) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + q * 8);
-            float4 b[NT];
+    // flattened (tap, 8-channel chunk) loop with the NEXT step's operands (LDS A fragment, L2 B fragments)
+    // fetched before the current step's MFMAs: one step has only 4*NT MFMAs, too few to hide an L2 round trip
+    {
+      const int nq = p.cslab >> 3;
+      const int total = p.KD * p.KH * p.KW * nq;
+      const float* abase = lds + hv * CS + 4 * lh;
+      const float* wbase = p.wp + ((size_t)(((slab * p.cslab) >> 2) + lh) * p.c2p + ch0 + li) * 4;
+      const size_t wtap = (size_t)(p.c1p >> 2) * p.c2p * 4;       // floats between taps
+      const size_t wq2 = (size_t)2 * p.c2p * 4;                    // floats between 8-channel chunks
+      int kd = 0, kh = 0, kw = 0, q = 0, tap = 0;
+      float4 a_cur = *reinterpret_cast<const float4*>(abase);
+      float4 b_cur[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              b[nt] = *reinterpret_cast<const float4*>(wrow + ((size_t)(2 * q) * p.c2p + nt * 32) * 4);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[nt].x, acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[nt].y, acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[nt].z, acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nt].w, acc[nt], 0, 0, 0);
+      for (int nt = 0; nt < NT; ++nt) b_cur[nt] = *reinterpret_cast<const float4*>(wbase + nt * 32 * 4);
+      for (int it = 0; it < total; ++it) {
+        if (++q == nq) {
+          q = 0;
+          ++tap;
+          if (++kw == p.KW) {
+            kw = 0;
+            if (++kh == p.KH) {
+              kh = 0;
+              ++kd;
+            }
           }
         }
+        float4 a_nxt = a_cur, b_nxt[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = b_cur[nt];
+        if (it + 1 < total) {
+          a_nxt = *reinterpret_cast<const float4*>(abase + ((kd * HH + kh) * HW + kw) * CS + q * 8);
+          const float* wr = wbase + (size_t)tap * wtap + (size_t)q * wq2;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = *reinterpret_cast<const float4*>(wr + nt * 32 * 4);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[nt].x, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[nt].y, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur[nt].z, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur[nt].w, acc[nt], 0, 0, 0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
+      }
+    }
 
     if (slab == p.nslab - 1) {
       const Tile tl = decode(tile);

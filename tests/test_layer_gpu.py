@@ -172,4 +172,5 @@ def test_data_parallel_two_ranks_on_one_gpu_matches_single_rank(tmp_path):
     assert dp0["nums"] == single["nums"]
     a, b = np.array(dp0["loss"]), np.array(single["loss"])
     assert abs(a[0] - b[0]) <= 1e-6 * b[0], (a, b)      # first layer: identical inputs, sums re-associated only
-    assert np.all(np.abs(a - b) <= 5e-2 * b), (a, b)    # later layers: plateau drift
+    assert np.all(np.abs(a - b) <= 1e-1 * b), (a, b)    # later layers: plateau drift
+    assert abs(a.sum() - b.sum()) <= 3e-2 * b.sum()
