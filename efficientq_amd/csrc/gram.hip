@@ -85,9 +85,10 @@ __device__ __forceinline__ float4 gram_fetch_cell(const GramParams& p, const Row
 constexpr int GT = 512;   // threads: 8 waves = 4 row sub-tiles x 2 column halves
 
 __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
-  __shared__ __attribute__((aligned(16))) float panI[KC * PS];
-  __shared__ __attribute__((aligned(16))) float panJ[KC * PS];
-  __shared__ float att_s[KC];
+  // double-buffered panels: chunk c+1 is written while chunk c is still being consumed (one barrier per chunk)
+  __shared__ __attribute__((aligned(16))) float panI[2][KC * PS];
+  __shared__ __attribute__((aligned(16))) float panJ[2][KC * PS];
+  __shared__ float att_s[2][KC];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -183,40 +184,64 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
     }
   const int fold = p.fold;
   int since = 0;
-  const float* pj = diag ? panI : panJ;
-
-  if (v_begin < v_end) prefetch(v_begin);
-  for (unsigned v0 = v_begin; v0 < v_end; v0 += KC) {
-    __syncthreads();  // previous chunk fully consumed
+  // sub-tiles made only of padding rows (>= E) are skipped: wave-uniform predicates
+  const bool rows_live = I * MB + wi * 32 < p.E;
+  const bool col_live[2] = {J * MB + (2 * wjh + 0) * 32 < p.E, J * MB + (2 * wjh + 1) * 32 < p.E};
+  auto stage = [&](int buf) {
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const int vv = vsub + 16 * ps;
-      *reinterpret_cast<float4*>(&panI[vv * PS + 4 * g]) = rI[ps];
-      if (!diag) *reinterpret_cast<float4*>(&panJ[vv * PS + 4 * g]) = rJ[ps];
+      *reinterpret_cast<float4*>(&panI[buf][vv * PS + 4 * g]) = rI[ps];
+      if (!diag) *reinterpret_cast<float4*>(&panJ[buf][vv * PS + 4 * g]) = rJ[ps];
     }
-    if (tid < KC) att_s[tid] = ratt;
-    __syncthreads();
-    if (v0 + KC < v_end) prefetch(v0 + KC);      // lands in registers under the MFMAs below
+    if (tid < KC) att_s[buf][tid] = ratt;
+  };
+
+  int buf = 0;
+  if (v_begin < v_end) {
+    prefetch(v_begin);
+    stage(0);
+  }
+  __syncthreads();
+  for (unsigned v0 = v_begin; v0 < v_end; v0 += KC, buf ^= 1) {
+    const bool more = v0 + KC < v_end;
+    if (more) prefetch(v0 + KC);                 // lands in registers under the MFMAs below
+    if (rows_live && col_live[0]) {
+      const float* pi = panI[buf];
+      const float* pj = diag ? panI[buf] : panJ[buf];
+      if (col_live[1]) {
 #pragma unroll 4
-    for (int s = 0; s < KC / 2; ++s) {
-      const int vv = 2 * s + lh;
-      const float a = panI[vv * PS + wi * 32 + li] * att_s[vv];
+        for (int s = 0; s < KC / 2; ++s) {
+          const int vv = 2 * s + lh;
+          const float a = pi[vv * PS + wi * 32 + li] * att_s[buf][vv];
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        const float b = pj[vv * PS + (2 * wjh + jt) * 32 + li];
-        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[jt], 0, 0, 0);
+          for (int jt = 0; jt < 2; ++jt) {
+            const float b = pj[vv * PS + (2 * wjh + jt) * 32 + li];
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[jt], 0, 0, 0);
+          }
+        }
+      } else {      // second column sub-tile is padding only
+#pragma unroll 4
+        for (int s = 0; s < KC / 2; ++s) {
+          const int vv = 2 * s + lh;
+          const float a = pi[vv * PS + wi * 32 + li] * att_s[buf][vv];
+          const float b = pj[vv * PS + (2 * wjh) * 32 + li];
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+        }
+      }
+      if (++since == fold) {
+        since = 0;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc64[jt][r] += (double)acc[jt][r];
+            acc[jt][r] = 0.0f;
+          }
       }
     }
-    if (++since == fold) {
-      since = 0;
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc64[jt][r] += (double)acc[jt][r];
-          acc[jt][r] = 0.0f;
-        }
-    }
+    if (more) stage(buf ^ 1);
+    __syncthreads();
   }
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt)

@@ -43,6 +43,25 @@ __device__ __forceinline__ double disc64(double x, double alpha, double lo, doub
   return r * d + lo;
 }
 
+// Same level index as disc64 (bit-exact), without the two IEEE fp64 divisions on the common path: the
+// quotient is formed with reciprocals (a few ulp off) and accepted only when it is provably on the same
+// side of every rounding boundary as the exact one; otherwise the exact divisions are redone.
+__device__ __forceinline__ double disc64_fast(double x, double alpha, double ralpha, double lo, double hi, double d,
+                                              double rd, double* idx) {
+  double t = fmin(fmax(x * ralpha, lo), hi);
+  const double u = (t - lo) * rd;
+  const double fr = u - floor(u);
+  // |u_exact - u| <= ~8 ulp(u) + the clamp edges; 1e-9 is far above that and far below any real margin
+  // (a few-ulp change of t at a clamp edge moves u by a few ulp next to an INTEGER, which rint absorbs)
+  const bool safe = fabs(fr - 0.5) > 1e-9 * (1.0 + u);
+  if (safe) {
+    const double r = rint(u);
+    *idx = r;
+    return r * d + lo;
+  }
+  return disc64(x, alpha, lo, hi, d, idx);
+}
+
 __global__ __launch_bounds__(TPB) void k_quant_dequant_f32(const float* __restrict__ x,
                                                            const float* __restrict__ alpha_dev, float lo,
                                                            float hi, float d, float* __restrict__ y,
@@ -124,6 +143,7 @@ __global__ __launch_bounds__(TPB) void k_reduce(const float* __restrict__ x, siz
   for (int s = 0; s < NS; ++s) acc[s] = 0.0;
   double alpha = 1.0;
   if (MODE == 2) alpha = *alpha_dev;
+  const double ralpha = 1.0 / alpha, rd = (MODE == 2) ? 1.0 / d : 1.0;
   const size_t nv = n / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   auto body = [&](float xf) {
@@ -135,7 +155,7 @@ __global__ __launch_bounds__(TPB) void k_reduce(const float* __restrict__ x, siz
       acc[1] += v * v;
     } else {
       double r;
-      double b = disc64(v, alpha, lo, hi, d, &r);
+      double b = disc64_fast(v, alpha, ralpha, lo, hi, d, rd, &r);
       acc[0] += b * v;
       acc[1] += b * b;
     }
@@ -165,6 +185,7 @@ __global__ __launch_bounds__(TPB) void k_fp_iter(const float* __restrict__ x, si
   __shared__ int s_last;
   if (st->done != 0) return;  // uniform across the grid
   const double alpha = st->alpha;
+  const double ralpha = 1.0 / alpha, rd = 1.0 / d;
   double acc[2] = {0.0, 0.0};
   const size_t nv = n / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -174,14 +195,14 @@ __global__ __launch_bounds__(TPB) void k_fp_iter(const float* __restrict__ x, si
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       double r;
-      const double b = disc64((double)e[k], alpha, lo, hi, d, &r);
+      const double b = disc64_fast((double)e[k], alpha, ralpha, lo, hi, d, rd, &r);
       acc[0] += b * (double)e[k];
       acc[1] += b * b;
     }
   }
   for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     double r;
-    const double b = disc64((double)x[i], alpha, lo, hi, d, &r);
+    const double b = disc64_fast((double)x[i], alpha, ralpha, lo, hi, d, rd, &r);
     acc[0] += b * (double)x[i];
     acc[1] += b * b;
   }
@@ -228,10 +249,11 @@ __global__ __launch_bounds__(FPS_T) void k_fp_small(const float* __restrict__ a,
   int it = 0, done = 0;
   while (!done) {
     acc[0] = acc[1] = 0.0;
+    const double ralpha = 1.0 / alpha, rd = 1.0 / d;
     for (size_t i = tid; i < n; i += FPS_T) {
       const double v = (double)src[i];
       double r;
-      const double bq = disc64(v, alpha, lo, hi, d, &r);
+      const double bq = disc64_fast(v, alpha, ralpha, lo, hi, d, rd, &r);
       acc[0] += bq * v;
       acc[1] += bq * bq;
     }

@@ -444,7 +444,10 @@ int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const f
                        (float)rho, (float)eta, Bm, ldb, c2p);
     EFFQ_LAUNCH_CHECK();
   }
-  if (c2p >= 128)
+  if (c2p >= 128 && ((n + 63) / 64) * (c2p / 128) < 200)   // too few 128x64 tiles to fill 256 CUs: 128x32 tiles
+    hipLaunchKernelGGL((k_prox_gemm<4, 1, 1>), dim3((n + 31) / 32, c2p / 128), dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2,
+                       has_bias ? 1 : 0, wstar, bstar);
+  else if (c2p >= 128)
     hipLaunchKernelGGL((k_prox_gemm<4, 1, 2>), dim3((n + 63) / 64, c2p / 128), dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2,
                        has_bias ? 1 : 0, wstar, bstar);
   else if (c2p == 64)
