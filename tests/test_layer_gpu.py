@@ -174,3 +174,25 @@ def test_data_parallel_two_ranks_on_one_gpu_matches_single_rank(tmp_path):
     assert abs(a[0] - b[0]) <= 1e-6 * b[0], (a, b)      # first layer: identical inputs, sums re-associated only
     assert np.all(np.abs(a - b) <= 1e-1 * b), (a, b)    # later layers: plateau drift
     assert abs(a.sum() - b.sum()) <= 3e-2 * b.sum()
+
+
+def test_cli_ptq_mission_writes_reference_artifacts(tmp_path):
+    """`entrance ptq` with the reference's flag names on a tiny synthetic problem: layer_loss.txt,
+    time_cost.txt, class_voxel_nums.txt and the three snapshots (uint8 weights in the int8 ones)."""
+    from efficientq_amd import entrance
+    snap = str(tmp_path / "snap")
+    entrance.main(["ptq", "--task", "lits", "--qconv", "effq", "--qlvl_w", "4", "--qlvl_a", "4", "--q_first", "256,-1",
+                   "--q_last", "256,-1", "--width", "8,16,8", "--depth", "1,1,1", "--init_stride", "1", "--nMod", "1",
+                   "--nClass", "3", "--blk", "mid", "--ds", "simple", "--hetero_dim", "--drop_rate", "0.5",
+                   "--lwq_batchsz", "2", "--lwq_patchsz", "32,32,32", "--synthetic", "--no_test", "--snap_dir", snap])
+    import os
+    for f in ("layer_loss.txt", "time_cost.txt", "class_voxel_nums.txt", "state_in_fp.pkl", "state_in_int8.pkl",
+              "state_in_int8_compress.npz"):
+        assert os.path.exists(os.path.join(snap, f)), f
+    lines = open(os.path.join(snap, "layer_loss.txt")).read().strip().split("\n")
+    assert len(lines) == 10 and lines[0].startswith(f"{'conv0.conv':45s}:")
+    sd = torch.load(os.path.join(snap, "state_in_int8.pkl"))["state_dict"]
+    w = sd["u_blocks.UResBlock1.Layer1.block1.conv.weight"]
+    assert w.dtype == torch.uint8 and int(w.max()) <= 3
+    fp = torch.load(os.path.join(snap, "state_in_fp.pkl"))["state_dict"]["u_blocks.UResBlock1.Layer1.block1.conv.weight"]
+    assert len(torch.unique(fp)) <= 4
