@@ -51,6 +51,160 @@ __global__ __launch_bounds__(256) void k_pack_weight_i8(const int8_t* __restrict
   }
 }
 
+// Packed layout for the wide-channel kernel: [tap][group g][k-half h][c2p][16 bytes], so that the B operand of one
+// MFMA is a 512-byte contiguous run per lane half (coalesced 16-byte loads straight from L2).
+__global__ __launch_bounds__(256) void k_pack_weight_i8g(const int8_t* __restrict__ Gq, int8_t* __restrict__ wq, int C1,
+                                                         int C2, int T, int c2p) {
+  const size_t total = (size_t)T * c2p * C1;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int CG = C1 / 32;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int b = (int)(e & 15);
+    size_t r = e >> 4;
+    const int j = (int)(r % c2p);
+    r /= c2p;
+    const int h = (int)(r & 1);
+    r >>= 1;
+    const int g = (int)(r % CG);
+    const int tap = (int)(r / CG);
+    const int c = 32 * g + 16 * h + b;
+    wq[e] = (j < C2) ? Gq[((size_t)j * C1 + c) * T + tap] : (int8_t)0;
+  }
+}
+
+// Wide-channel variant (C1 = 128 / 256): the B operands no longer fit in registers; they stream from L2
+// one (tap, group) step ahead of the MFMA that consumes them.  Everything else as in k_conv3d_i8.
+template <int CG>
+__global__ __launch_bounds__(256, (CG <= 4) ? 2 : 1) void k_conv3d_i8g(ConvI8Params p) {
+  constexpr int VS = 32 * CG + 16;
+  constexpr int NHL = (I_NH * 2 * CG + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) int8_t dyn_lds[];
+  int8_t* halo = dyn_lds;                                       // I_NH * VS bytes
+  float* tb = reinterpret_cast<float*>(dyn_lds + ((I_NH * VS + 15) / 16) * 16);   // 128 * I_TS floats
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ch0 = blockIdx.y * 32;
+  const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per;
+  const int t_end = (t_begin + per < p.ntiles) ? t_begin + per : p.ntiles;
+  const float scale = (float)((double)(*p.act_alpha) * (double)(float)p.wstate->alpha * p.inv_levels);
+  const float bv = (p.bias != nullptr) ? p.bias[ch0 + li] : 0.0f;
+  // B operand of step (tap, g): wq[((tap*CG + g)*2 + lh) * c2p + ch0 + li] (16-byte units)
+  const v4i* wbase = reinterpret_cast<const v4i*>(p.wq) + (size_t)lh * p.c2p + ch0 + li;
+  const size_t wstep = (size_t)2 * p.c2p;
+
+  struct Tile {
+    int n, od0, oh0, ow0;
+  };
+  auto decode = [&](int tile) {
+    Tile r;
+    int t = tile;
+    r.ow0 = (t % p.tiles_w) * ITW;
+    t /= p.tiles_w;
+    r.oh0 = (t % p.tiles_h) * ITH;
+    t /= p.tiles_h;
+    r.od0 = (t % p.tiles_d) * ITD;
+    r.n = t / p.tiles_d;
+    return r;
+  };
+  auto load_halo = [&](const Tile& tl, v4i(&hreg)[NHL]) {
+    const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u / (2 * CG), part = u % (2 * CG);
+      const int hw = vox % I_HW;
+      const int t2 = vox / I_HW;
+      const int hh = t2 % I_HH, hd = t2 / I_HH;
+      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+      hreg[k] = v4i{0, 0, 0, 0};
+      if (u < I_NH * 2 * CG && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+        hreg[k] = *reinterpret_cast<const v4i*>(p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 +
+                                                part * 16);
+    }
+  };
+  auto load_y = [&](const Tile& tl, float4(&yv)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u >> 3;
+      const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
+      yv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (od < p.OD && oh < p.OH && ow < p.OW)
+        yv[k] = *reinterpret_cast<const float4*>(p.y + ((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 +
+                                                 ch0 + (u & 7) * 4);
+    }
+  };
+
+  const int hv = (wid * I_HH + (li >> 3)) * I_HW + (li & 7);
+  double l0 = 0.0;
+  v4i hreg[NHL];
+  float4 ynext[4], ycur[4];
+  if (t_begin < t_end) {
+    const Tile t0 = decode(t_begin);
+    load_halo(t0, hreg);
+    load_y(t0, ynext);
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      if (u < I_NH * 2 * CG) *reinterpret_cast<v4i*>(&halo[(u / (2 * CG)) * VS + (u % (2 * CG)) * 16]) = hreg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ycur[k] = ynext[k];
+    __syncthreads();
+    if (tile + 1 < t_end) {
+      const Tile tn = decode(tile + 1);
+      load_halo(tn, hreg);
+      load_y(tn, ynext);
+    }
+    v16i acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0;
+    v4i b_cur = wbase[0];
+#pragma unroll 1
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const int8_t* arow = halo + (hv + (kd * I_HH + kh) * I_HW + kw) * VS + 16 * lh;
+#pragma unroll
+      for (int g = 0; g < CG; ++g) {
+        const int step = tap * CG + g;
+        const int nxt = (step + 1 < 27 * CG) ? step + 1 : step;
+        const v4i b_nxt = wbase[(size_t)nxt * wstep];
+        const v4i a = *reinterpret_cast<const v4i*>(arow + 32 * g);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_cur, acc, 0, 0, 0);
+        b_cur = b_nxt;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      tb[(wid * 32 + i) * I_TS + li] = (float)acc[r] * scale + bv;
+    }
+    __syncthreads();
+    const Tile tl = decode(tile);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u >> 3, c4 = u & 7;
+      const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
+      if (od < p.OD && oh < p.OH && ow < p.OW) {
+        const float4 o = *reinterpret_cast<const float4*>(&tb[vox * I_TS + c4 * 4]);
+        const float d0 = o.x - ycur[k].x, d1 = o.y - ycur[k].y, d2 = o.z - ycur[k].z, d3 = o.w - ycur[k].w;
+        l0 += ((double)(d0 * d0) + (double)(d1 * d1)) + ((double)(d2 * d2) + (double)(d3 * d3));
+      }
+    }
+  }
+  double v[2] = {l0, l0};
+  grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
+                     gridDim.x * gridDim.y);
+}
+
 template <int CG>
 __global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Params p) {
   constexpr int VS = 32 * CG + 16;                         // bytes per halo voxel in LDS
@@ -196,7 +350,7 @@ struct I8Plan {
 static int i8_plan(const effq_geom* g, I8Plan* pl) {
   EFFQ_CHECK_ARG(g != nullptr);
   EFFQ_CHECK_ARG(g->KD == 3 && g->KH == 3 && g->KW == 3 && g->SD == 1 && g->SH == 1 && g->SW == 1);
-  EFFQ_CHECK_ARG(g->C1 == 32 || g->C1 == 64);
+  EFFQ_CHECK_ARG(g->C1 == 32 || g->C1 == 64 || g->C1 == 128 || g->C1 == 256);
   EFFQ_CHECK_ARG(g->C2 > 0 && (g->C2 % 32) == 0);
   EFFQ_CHECK_ARG(g->N > 0 && g->D > 0 && g->H > 0 && g->W > 0 && g->PD >= 0 && g->PH >= 0 && g->PW >= 0);
   ConvI8Params& p = pl->p;
@@ -212,7 +366,7 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
   EFFQ_CHECK_ARG(nt < (1ll << 30));
   p.ntiles = (int)nt;
   const int ny = p.C2 / 32;
-  const int wg_per_cu = (g->C1 == 32) ? 2 : 1;
+  const int wg_per_cu = (g->C1 == 32 || g->C1 == 128) ? 2 : 1;
   int gx = (256 * wg_per_cu + ny - 1) / ny;
   if (gx < 32) gx = 32;
   if (gx > p.ntiles) gx = p.ntiles;
@@ -231,7 +385,7 @@ extern "C" {
 int effq_conv_i8_supported(const effq_geom* g, int act_levels, int w_levels) {
   if (g == nullptr) return 0;
   if (!(g->KD == 3 && g->KH == 3 && g->KW == 3 && g->SD == 1 && g->SH == 1 && g->SW == 1)) return 0;
-  if (!(g->C1 == 32 || g->C1 == 64) || (g->C2 % 32) != 0) return 0;
+  if (!(g->C1 == 32 || g->C1 == 64 || g->C1 == 128 || g->C1 == 256) || (g->C2 % 32) != 0) return 0;
   if (act_levels < 2 || act_levels > 128 || w_levels < 2 || w_levels > 128) return 0;
   // int32 accumulator range: 27*C1 products of at most (La-1)*(Lw-1)
   if ((double)27 * g->C1 * (act_levels - 1) * (w_levels - 1) >= 2147483647.0) return 0;
@@ -277,13 +431,29 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
   {
     size_t nb = (pl.wq_bytes + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_pack_weight_i8, dim3((unsigned)nb), dim3(256), 0, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
+    if (p.C1 <= 64)
+      hipLaunchKernelGGL(k_pack_weight_i8, dim3((unsigned)nb), dim3(256), 0, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
+    else
+      hipLaunchKernelGGL(k_pack_weight_i8g, dim3((unsigned)nb), dim3(256), 0, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
     EFFQ_LAUNCH_CHECK();
   }
-  if (p.C1 == 32)
+  if (p.C1 == 32) {
     hipLaunchKernelGGL(k_conv3d_i8<1>, pl.grid, dim3(256), 0, st, p);
-  else
+  } else if (p.C1 == 64) {
     hipLaunchKernelGGL(k_conv3d_i8<2>, pl.grid, dim3(256), 0, st, p);
+  } else {
+    const int cg = p.C1 / 32;
+    const size_t lds = (size_t)((I_NH * (32 * cg + 16) + 15) / 16) * 16 + (size_t)128 * I_TS * sizeof(float);
+    if (cg == 4) {
+      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_i8g<4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_conv3d_i8g<4>, pl.grid, dim3(256), lds, st, p);
+    } else {
+      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_i8g<8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_conv3d_i8g<8>, pl.grid, dim3(256), lds, st, p);
+    }
+  }
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

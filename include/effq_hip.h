@@ -170,7 +170,7 @@ int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* 
  * activations and projected weights: x = alpha_a*k/(La-1) with level ids k (uint8, NDHWC) and
  * G = alpha_w*j'/(Lw-1) with Gq = j' (int8, reference weight layout).  The contraction runs on the i8
  * matrix cores with exact int32 accumulation; out = f32(alpha_a)*f32(alpha_w)/((La-1)(Lw-1)) * acc + bias.
- * Supported: 3x3x3, stride 1, C1 in {32,64}, C2 % 32 == 0, levels <= 128 (query effq_conv_i8_supported).
+ * Supported: 3x3x3, stride 1, C1 in {32,64,128,256}, C2 % 32 == 0, levels <= 128 (query effq_conv_i8_supported).
  * alpha_a: device float; alpha_w: w_state_dev->alpha.  sqerr_out[0] = sqerr_out[1] = sum (out-y)^2. */
 int effq_conv_i8_supported(const effq_geom* g, int act_levels, int w_levels);
 size_t effq_conv_i8_ws_bytes(const effq_geom* g);

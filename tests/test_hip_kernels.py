@@ -296,7 +296,8 @@ def test_single_launch_weight_fixed_point_matches_goldens(ops, gold, L):
 
 @pytest.mark.parametrize("c1,c2,La,Lw,sp", [(32, 32, 4, 4, (8, 8, 16)), (32, 64, 16, 16, (9, 7, 11)),
                                              (64, 64, 4, 4, (8, 8, 8)), (64, 32, 16, 4, (5, 6, 9)),
-                                             (32, 32, 128, 128, (4, 4, 8))])
+                                             (32, 32, 128, 128, (4, 4, 8)), (128, 128, 4, 4, (4, 8, 8)),
+                                             (256, 64, 16, 16, (4, 4, 8)), (128, 32, 16, 4, (5, 6, 9))])
 def test_exact_int_conv_step_equals_fp32_path(ops, c1, c2, La, Lw, sp):
     """conv3d_calib_step_i8 (i8 MFMA, exact int32 accumulation) against conv3d_quant_calib_step on the
     SAME quantised operands: identical loss up to the fp32 path's own rounding (<= 2e-6 relative)."""
