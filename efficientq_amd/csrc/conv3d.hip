@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
         const int hh = t2 % HH, hd = t2 / HH;
         const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
         const int c = slab * p.cslab + c4 * 4;
-        if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && c < p.C1) {
+        if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && c < p.C1 && p.debug != 2) {
           const float* src = p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 + c;
           if (vec_ok) {
             hreg[k] = *reinterpret_cast<const float4*>(src);
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int oh = tl.oh0 + (i >> 3), ow = tl.ow0 + (i & 7);
         yv[nt][r] = 0.0f;
-        if (ch < p.C2 && od < p.OD && oh < p.OH && ow < p.OW)
+        if (ch < p.C2 && od < p.OD && oh < p.OH && ow < p.OW && p.debug != 3)
           yv[nt][r] = p.y[((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 + ch];
       }
     }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
 #pragma unroll
     for (int q = 0; q < G_MAXH; ++q) {
       const int u = tid + q * 256;
-      if (u < nh4) {
+      if (u < nh4 && p.debug != 4) {
         float4 v = hreg[q];
         if (p.act_on) {
           v.x = act_qd(v.x, alpha, p.act_d);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
     // fetched before the current step's MFMAs: one step has only 4*NT MFMAs, too few to hide an L2 round trip
     {
       const int nq = p.cslab >> 3;
-      const int total = p.KD * p.KH * p.KW * nq;
+      const int total = (p.debug == 1) ? 0 : p.KD * p.KH * p.KW * nq;
       const float* abase = lds + hv * CS + 4 * lh;
       const float* wbase = p.wp + ((size_t)(((slab * p.cslab) >> 2) + lh) * p.c2p + ch0 + li) * 4;
       const size_t wtap = (size_t)(p.c1p >> 2) * p.c2p * 4;       // floats between taps

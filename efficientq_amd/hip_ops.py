@@ -73,6 +73,12 @@ class HipOps:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def side_stream(self):
+        """A second HIP stream of this device for work that is independent of the calibration stream."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
+
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
         cur = self._ws.get(key)
         if cur is None or cur.numel() < nbytes:
@@ -213,12 +219,12 @@ class HipOps:
 
     # -- a7 -----------------------------------------------------------------------------------
     def spd_inverse(self, A0: torch.Tensor, has_bias: bool, rho: float, eta: float,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, ws_key: str = "inv") -> torch.Tensor:
         n = A0.shape[0]
         A0 = self._f32(A0)
         if out is None:     # n rows of effq_ainv_ld(n) floats (zero padded, 16-byte aligned rows)
             out = torch.empty(n, self.lib.effq_ainv_ld(n), dtype=torch.float32, device=self.device)
-        ws = self._workspace("inv", self.lib.effq_spd_inverse_ws_bytes(n))
+        ws = self._workspace(ws_key, self.lib.effq_spd_inverse_ws_bytes(n))
         check(self.lib.effq_spd_inverse(_ptr(A0), n, int(has_bias), rho, eta, _ptr(out), _ptr(ws), ws.numel(),
                                         self.stream), "effq_spd_inverse")
         return out

@@ -265,13 +265,36 @@ class EfficientQConvHIP(PTQConv):
         st_w = ops.new_fp_state()
         Gq = torch.empty(W0.shape, dtype=torch.int8, device=dev) if use_i8 else None
         fp_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        # A = A0 + rho*I' + eta*I changes only with rho, and the rho schedule is known up front (5 values per
+        # layer): the first inverse is formed on the calibration stream, the later ones on a side stream under
+        # the ADMM iterations that precede their first use (EfficientQConv.py:129-137 fixes when that is).
+        rhos, r_ = [], rho
+        for i in range(self.lwq_iter):
+            if not rhos or rhos[-1] != r_:
+                rhos.append(r_)
+            if i % RHO_PERIOD == 0:
+                r_ = r_ * 2 if r_ * 2 <= rho_m else rho_m
+        inv_of = {rhos[0]: (ops.spd_inverse(A0, has_b, rhos[0], eta), None)}
+        side = getattr(ops, "side_stream", lambda: None)()
+        if side is not None and len(rhos) > 1:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for r_ in rhos[1:]:
+                    buf = ops.spd_inverse(A0, has_b, r_, eta, ws_key="inv_side")
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    inv_of[r_] = (buf, ev)
         Ainv, rho_of_inv = None, None
         guess = 16
         a_w = 1.0
         w_iters, hist = [], []
         for i in range(self.lwq_iter):                                     # (:99-144)
             if rho_of_inv != rho:      # A changes only with rho: 5 inverses per layer, not 200 LU solves
-                Ainv = ops.spd_inverse(A0, has_b, rho, eta, out=Ainv)
+                if rho not in inv_of:
+                    inv_of[rho] = (ops.spd_inverse(A0, has_b, rho, eta), None)
+                Ainv, ev = inv_of[rho]
+                if ev is not None:
+                    torch.cuda.current_stream(dev).wait_event(ev)
                 rho_of_inv = rho
             ops.prox_solve(B0, Ainv, W0, b0, G, dual, rho, eta, wstar, bstar)
             it_w = ops.weight_fixed_point(wstar, dual, v, self.qlvl_w, st_w, guess)   # (:108) no host sync
@@ -296,6 +319,8 @@ class EfficientQConvHIP(PTQConv):
             if i % RHO_PERIOD == 0:
                 rho = rho * 2 if rho * 2 <= rho_m else rho_m
 
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
         a_w, _, _ = ops.read_fp_state(st_w)                                # one sync per layer
         if fp_err.item() != 0:                                             # layer_helper.py:62-64
             raise RuntimeWarning(f'Exceed maximum iteration ({100 * self.qlvl_w}) for alpha optimization')
