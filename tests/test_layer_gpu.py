@@ -196,3 +196,26 @@ def test_cli_ptq_mission_writes_reference_artifacts(tmp_path):
     assert w.dtype == torch.uint8 and int(w.max()) <= 3
     fp = torch.load(os.path.join(snap, "state_in_fp.pkl"))["state_dict"]["u_blocks.UResBlock1.Layer1.block1.conv.weight"]
     assert len(torch.unique(fp)) <= 4
+
+
+def test_mixed_precision_search_respects_budget_and_improves_with_bits():
+    """Row f4 harness on the tiny net: the greedy assignment stays within the bit budget, uses only the
+    candidate levels, and more bits never make the calibrated network worse (sum of layer losses)."""
+    from efficientq_amd import calibrate as K, config as Cf, mixed, synth
+    args = Cf.make_args(dict(Cf.TINY_NET, width="8,16,8"), 4, 4)
+    QConv, _, kwQ = Cf.get_conv_class(args)
+
+    def build():
+        m = Cf.get_model_cube(args, QConv, kwQ)[0]["model"]
+        synth.randomise_network(m, 3)
+        m.eval(); K.search_fold_and_remove_bn(m); m.to(DEV); K.set_name(m)
+        return m
+    vols = torch.randn(2, 1, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(DEV)
+    res = mixed.search(build, vols, "lits", args.init_stride, [2.0, 3.0, 4.0], levels=(4, 8, 16))
+    assert [r["budget_bits"] for r in res] == [2.0, 3.0, 4.0]
+    for r in res:
+        assert r["avg_bits"] <= r["budget_bits"] + 1e-9
+        assert set(r["levels"].values()) <= {4, 8, 16} and len(r["levels"]) == 8
+    assert set(res[0]["levels"].values()) == {4} and set(res[2]["levels"].values()) == {16}
+    assert res[2]["sum_layer_loss"] < res[0]["sum_layer_loss"]
+    assert res[1]["sum_layer_loss"] <= res[0]["sum_layer_loss"] * 1.02
