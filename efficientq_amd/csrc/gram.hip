@@ -11,6 +11,7 @@
 // v_mfma_f32_32x32x2_f32 with K = voxels.  Partial blocks go to per-split slabs; a second
 // kernel adds the (fp64) slabs in a fixed order (deterministic), mirrors, scales by 2 and
 // scatters into the reference's (c,kd,kh,kw)+bias row order.
+#include <stdlib.h>
 #include "common.h"
 
 namespace effq {
@@ -32,6 +33,7 @@ struct GramParams {
   int nsplit;
   long long vox_per_split;
   int fold;
+  int debug;   // profiling ablations (EFFQ_GRAM_DEBUG): 1 no MFMA, 2 no global loads, 3 no LDS stores
   double* slabs;
 };
 
@@ -205,12 +207,12 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
   __syncthreads();
   for (unsigned v0 = v_begin; v0 < v_end; v0 += KC, buf ^= 1) {
     const bool more = v0 + KC < v_end;
-    if (more) prefetch(v0 + KC);                 // lands in registers under the MFMAs below
-    if (rows_live && col_live[0]) {
+    if (more && p.debug != 2) prefetch(v0 + KC);  // lands in registers under the MFMAs below
+    if (rows_live && col_live[0] && p.debug != 1) {
       const float* pi = panI[buf];
       const float* pj = diag ? panI[buf] : panJ[buf];
       if (col_live[1]) {
-#pragma unroll 4
+#pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
           const int vv = 2 * s + lh;
           const float a = pi[vv * PS + wi * 32 + li] * att_s[buf][vv];
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
           }
       }
     }
-    if (more) stage(buf ^ 1);
+    if (more && p.debug != 3) stage(buf ^ 1);
     __syncthreads();
   }
 #pragma unroll
@@ -372,6 +374,10 @@ int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc
   if (ws_bytes < need) {
     set_error("gram: workspace %zu < required %zu", ws_bytes, need);
     return EFFQ_ERR_WORKSPACE;
+  }
+  {
+    const char* dbg = getenv("EFFQ_GRAM_DEBUG");
+    p.debug = dbg ? atoi(dbg) : 0;
   }
   p.x = x_ndhwc;
   p.att = att;
