@@ -12,6 +12,7 @@
 // groups of its 32 output channels -- live in REGISTERS for the whole kernel (27*CG*4 VGPRs), the
 // level-id halo tile (6x6x10 voxels x C1 bytes) is staged through LDS with a 16-byte pad per voxel,
 // and the next tile's halo + targets are prefetched into registers under the current tile's MFMAs.
+#include <stdlib.h>
 #include "common.h"
 
 namespace effq {
@@ -36,6 +37,7 @@ struct ConvI8Params {
   double* partials;
   unsigned int* ticket;
   double* sqerr;
+  int debug;   // profiling ablations (EFFQ_I8_DEBUG): 1 no MFMA loop, 2 no halo loads, 3 no target loads
 };
 
 __global__ __launch_bounds__(256) void k_pack_weight_i8(const int8_t* __restrict__ Gq, int8_t* __restrict__ wq, int C1,
@@ -341,6 +343,136 @@ __global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Para
                      gridDim.x * gridDim.y);
 }
 
+
+// 32-input-channel variant tuned for memory-level parallelism (the kernel is HBM-latency bound):
+//  * B operands (27 KB) live in LDS, laid out [tap][k-half][out channel][16 B] (conflict-free ds_read_b128),
+//    which frees ~108 VGPRs -> three workgroups per CU;
+//  * two register sets alternate roles so that halo and targets are fetched TWO tiles ahead;
+//  * targets are fetched in accumulator layout (16 dword loads per lane, 128-byte segments), so the epilogue
+//    needs no LDS transpose and a tile costs two barriers.
+__global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
+  constexpr int VS = 48;
+  constexpr int NHL = (I_NH * 2 + 255) / 256;   // 3
+  __shared__ __attribute__((aligned(16))) int8_t wl[27 * 2 * 32 * 16];
+  __shared__ __attribute__((aligned(16))) int8_t halo[I_NH * VS];
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ch0 = blockIdx.y * 32;
+  const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per;
+  const int t_end = (t_begin + per < p.ntiles) ? t_begin + per : p.ntiles;
+
+  // stage this workgroup's weights once: wl[tap][h][j] <- wq[(tap*c2p + ch0 + j)*32 + 16h]
+  for (int u = tid; u < 27 * 2 * 32; u += 256) {
+    const int j = u & 31, h = (u >> 5) & 1, tap = u >> 6;
+    *reinterpret_cast<v4i*>(&wl[u * 16]) =
+        *reinterpret_cast<const v4i*>(p.wq + ((size_t)(tap * p.c2p + ch0 + j) * 32 + 16 * h));
+  }
+  const float scale = (float)((double)(*p.act_alpha) * (double)(float)p.wstate->alpha * p.inv_levels);
+  const float bv = (p.bias != nullptr) ? p.bias[ch0 + li] : 0.0f;
+
+  struct Tile {
+    int n, od0, oh0, ow0;
+  };
+  auto decode = [&](int tile) {
+    Tile r;
+    int t = tile;
+    r.ow0 = (t % p.tiles_w) * ITW;
+    t /= p.tiles_w;
+    r.oh0 = (t % p.tiles_h) * ITH;
+    t /= p.tiles_h;
+    r.od0 = (t % p.tiles_d) * ITD;
+    r.n = t / p.tiles_d;
+    return r;
+  };
+  struct Regs {
+    v4i h[NHL];
+    float y[16];
+  };
+  auto fetch = [&](int tile, Regs& R) {
+    const Tile tl = decode(tile);
+    const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u >> 1, part = u & 1;
+      const int hw = vox % I_HW;
+      const int t2 = vox / I_HW;
+      const int hh = t2 % I_HH, hd = t2 / I_HH;
+      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+      R.h[k] = v4i{0, 0, 0, 0};
+      if (u < I_NH * 2 && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && p.debug != 2)
+        R.h[k] = *reinterpret_cast<const v4i*>(p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * 32 + part * 16);
+    }
+    const int od = tl.od0 + wid;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int oh = tl.oh0 + (i >> 3), ow = tl.ow0 + (i & 7);
+      R.y[r] = 0.0f;
+      if (od < p.OD && oh < p.OH && ow < p.OW && p.debug != 3)
+        R.y[r] = p.y[((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 + ch0 + li];
+    }
+  };
+
+  const int hv = (wid * I_HH + (li >> 3)) * I_HW + (li & 7);
+  double l0 = 0.0;
+  // one tile: store X's halo, refill X with tile+2, MFMAs, register epilogue against X's (saved) targets
+  auto body = [&](int tile, Regs& X) {
+    __syncthreads();                                       // previous tile's MFMAs are done with the halo
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      if (u < I_NH * 2) *reinterpret_cast<v4i*>(&halo[(u >> 1) * VS + (u & 1) * 16]) = X.h[k];
+    }
+    float ycur[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ycur[r] = X.y[r];
+    __syncthreads();
+    if (tile + 2 < t_end) fetch(tile + 2, X);              // two tiles ahead, into the set just consumed
+    v16i acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0;
+    if (p.debug != 1)
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const v4i a = *reinterpret_cast<const v4i*>(halo + (hv + (kd * I_HH + kh) * I_HW + kw) * VS + 16 * lh);
+      const v4i b = *reinterpret_cast<const v4i*>(&wl[((tap * 2 + lh) * 32 + li) * 16]);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+    }
+    const Tile tl = decode(tile);
+    const int od = tl.od0 + wid;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int oh = tl.oh0 + (i >> 3), ow = tl.ow0 + (i & 7);
+      if (od < p.OD && oh < p.OH && ow < p.OW) {
+        const float d = ((float)acc[r] * scale + bv) - ycur[r];
+        l0 += (double)(d * d);
+      }
+    }
+  };
+
+  Regs A, B;
+#pragma unroll
+  for (int k = 0; k < NHL; ++k) A.h[k] = B.h[k] = v4i{0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) A.y[r] = B.y[r] = 0.0f;
+  if (t_begin < t_end) fetch(t_begin, A);
+  if (t_begin + 1 < t_end) fetch(t_begin + 1, B);
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    body(tile, A);
+    if (tile + 1 < t_end) body(tile + 1, B);
+  }
+  double v[2] = {l0, l0};
+  grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
+                     gridDim.x * gridDim.y);
+}
+
 struct I8Plan {
   ConvI8Params p;
   dim3 grid;
@@ -366,7 +498,7 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
   EFFQ_CHECK_ARG(nt < (1ll << 30));
   p.ntiles = (int)nt;
   const int ny = p.C2 / 32;
-  const int wg_per_cu = (g->C1 == 32 || g->C1 == 128) ? 2 : 1;
+  const int wg_per_cu = (g->C1 == 32) ? 3 : (g->C1 == 128) ? 2 : 1;
   int gx = (256 * wg_per_cu + ny - 1) / ny;
   if (gx < 32) gx = 32;
   if (gx > p.ntiles) gx = p.ntiles;
@@ -426,6 +558,10 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
   p.wstate = w_state_dev;
   p.inv_levels = 1.0 / ((double)(act_levels - 1) * (double)(w_levels - 1));
   p.sqerr = sqerr_out;
+  {
+    const char* dbg = getenv("EFFQ_I8_DEBUG");
+    p.debug = dbg ? atoi(dbg) : 0;
+  }
   hipStream_t st = as_stream(stream);
   EFFQ_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned int), st));
   {
@@ -438,7 +574,10 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
     EFFQ_LAUNCH_CHECK();
   }
   if (p.C1 == 32) {
-    hipLaunchKernelGGL(k_conv3d_i8<1>, pl.grid, dim3(256), 0, st, p);
+    if (getenv("EFFQ_I8_REGS") != nullptr)      // register-resident variant kept for A/B comparison
+      hipLaunchKernelGGL(k_conv3d_i8<1>, pl.grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL(k_conv3d_i8l, pl.grid, dim3(256), 0, st, p);
   } else if (p.C1 == 64) {
     hipLaunchKernelGGL(k_conv3d_i8<2>, pl.grid, dim3(256), 0, st, p);
   } else {
