@@ -116,15 +116,24 @@ class OpTimer:
 
     def summary(self):
         rows = []
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        except (OSError, ValueError):
+            traffic = {}
         for key, pairs in self.rec.items():
             ms = [a.elapsed_time(b) for a, b in pairs]
             bound, work, pname, peak, unit, label = self._work(key)
             avg = sum(ms) / len(ms)
             ach = work / (avg * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
             side = key[0].endswith("@side")
+            tkey = key[0].replace("@side", "") + "|" + ",".join(str(v) for v in key[1:])
+            tr = traffic.get(tkey)
             rows.append(dict(kernel=label + (" [side stream, overlapped with the ADMM iterations]" if side else ""),
                              bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
-                             frac=round(ach / peak, 4), traffic=None, launches=len(ms), avg_ms=round(avg, 4),
+                             frac=round(ach / peak, 4),
+                             traffic=(dict(bytes_per_launch=tr["bytes"], algorithmic_bytes=tr["algorithmic_bytes"],
+                                           source=tr["source"]) if tr else None),
+                             launches=len(ms), avg_ms=round(avg, 4),
                              total_ms=round(sum(ms), 1), work_per_launch=work, overlapped=side))
         rows.sort(key=lambda r: (r["overlapped"], -r["total_ms"]))
         if not rows:
