@@ -131,8 +131,9 @@ class OpTimer:
             rows.append(dict(kernel=label + (" [side stream, overlapped with the ADMM iterations]" if side else ""),
                              bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
                              frac=round(ach / peak, 4),
-                             traffic=(dict(bytes_per_launch=tr["bytes"], algorithmic_bytes=tr["algorithmic_bytes"],
-                                           source=tr["source"]) if tr else None),
+                             traffic=(tr["bytes"] if tr else None),      # HBM-side bytes per launch (PMC passes)
+                             traffic_algorithmic=(tr["algorithmic_bytes"] if tr else None),
+                             traffic_source=(tr["source"] if tr else None),
                              launches=len(ms), avg_ms=round(avg, 4),
                              total_ms=round(sum(ms), 1), work_per_launch=work, overlapped=side))
         rows.sort(key=lambda r: (r["overlapped"], -r["total_ms"]))
