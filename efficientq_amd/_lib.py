@@ -63,6 +63,8 @@ SIGNATURES = {
     "effq_alpha_fixed_point": (_I, [_P, _SZ, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
     "effq_fp_small_max": (_SZ, []),
     "effq_fixed_point_small": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P]),
+    "effq_fp_coop_max": (_SZ, []),
+    "effq_fixed_point_coop": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _P]),
     "effq_fp_check": (_I, [_P, _P, _P]),
     "effq_gram_ws_bytes": (_SZ, [_GP, _I]),
     "effq_gram_accum": (_I, [_P, _P, _P, _GP, _I, _P, _P, _I, _P, _SZ, _P]),

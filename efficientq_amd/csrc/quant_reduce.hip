@@ -285,6 +285,119 @@ __global__ __launch_bounds__(FPS_T) void k_fp_small(const float* __restrict__ a,
   }
 }
 
+
+// ---- cooperative whole-fixed-point kernel for larger tensors --------------------------------------
+// G <= 64 workgroups of 1024 threads, one per CU, each owning a contiguous slice of v that stays in LDS for
+// all iterations.  Per iteration every workgroup publishes its two partial sums, all meet at a grid
+// barrier, and EVERY workgroup adds the G partials in workgroup order (identical alpha everywhere, run-to-
+// run and rank-to-rank deterministic -- replicated data-parallel ranks must stay bit-identical).
+// Grid barrier: monotonic agent-scope counter, release fence before the arrive, relaxed polling with
+// s_sleep, acquire fence after (cdna_hip_programming.md Guideline 16 / microarch "barrier-counter").
+// Every spin is bounded: on time-out the state is marked done=3 and all workgroups leave.
+constexpr int FPC_T = 1024;
+constexpr int FPC_SLICE = 27648;          // floats per workgroup kept in LDS (108 KiB)
+constexpr int FPC_MAXG = 64;
+constexpr unsigned FPC_SPIN_LIMIT = 1u << 24;
+
+__device__ __forceinline__ bool fpc_barrier(unsigned int* counter, unsigned target, int* s_fail) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > FPC_SPIN_LIMIT) {
+        *s_fail = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  return *s_fail == 0;
+}
+
+__global__ __launch_bounds__(FPC_T) void k_fp_coop(const float* __restrict__ a, const float* __restrict__ b2,
+                                                   float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
+                                                   double hi, double d, double tol, int max_iter, double* partials,
+                                                   unsigned int* counter) {
+  extern __shared__ __attribute__((aligned(16))) float vs[];      // this workgroup's slice of v
+  __shared__ double smem[2 * 16];
+  __shared__ int s_fail;
+  const int tid = threadIdx.x, G = gridDim.x, wg = blockIdx.x;
+  const size_t per = (n + G - 1) / G;
+  const size_t s0 = (size_t)wg * per, s1 = (s0 + per < n) ? s0 + per : n;
+  const int cnt = (s1 > s0) ? (int)(s1 - s0) : 0;
+  if (tid == 0) s_fail = 0;
+  double acc[2] = {0.0, 0.0};
+  for (int i = tid; i < cnt; i += FPC_T) {
+    const float v = (b2 != nullptr) ? (a[s0 + i] + b2[s0 + i]) : a[s0 + i];
+    if (v_out != nullptr) v_out[s0 + i] = v;
+    vs[i] = v;
+    acc[0] += fabs((double)v);
+  }
+  block_sum<2>(acc, smem);
+  unsigned epoch = 0;
+  // partials layout: [parity][wg][2]
+  if (tid == 0) partials[(0 * FPC_MAXG + wg) * 2 + 0] = acc[0];
+  if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail)) {
+    if (wg == 0 && tid == 0) st->done = 3;
+    return;
+  }
+  double tot = 0.0;
+  for (int g = 0; g < G; ++g) tot += __hip_atomic_load(&partials[(0 * FPC_MAXG + g) * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double alpha = tot / (double)n, alpha_prev = -999.0;
+  int it = 0, done = 0;
+  double last0 = 0.0, last1 = 0.0;
+  while (!done) {
+    const int par = (it + 1) & 1;          // parity 0 was used by the abs-sum epoch
+    acc[0] = acc[1] = 0.0;
+    const double ralpha = 1.0 / alpha, rd = 1.0 / d;
+    for (int i = tid; i < cnt; i += FPC_T) {
+      const double v = (double)vs[i];
+      double r;
+      const double bq = disc64_fast(v, alpha, ralpha, lo, hi, d, rd, &r);
+      acc[0] += bq * v;
+      acc[1] += bq * bq;
+    }
+    block_sum<2>(acc, smem);
+    if (tid == 0) {
+      partials[(par * FPC_MAXG + wg) * 2 + 0] = acc[0];
+      partials[(par * FPC_MAXG + wg) * 2 + 1] = acc[1];
+    }
+    if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail)) {
+      if (wg == 0 && tid == 0) st->done = 3;
+      return;
+    }
+    double t0 = 0.0, t1 = 0.0;
+    for (int g = 0; g < G; ++g) {
+      t0 += __hip_atomic_load(&partials[(par * FPC_MAXG + g) * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t1 += __hip_atomic_load(&partials[(par * FPC_MAXG + g) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double a_new = t0 / t1;
+    alpha_prev = alpha;
+    ++it;
+    if (it >= max_iter)
+      done = 2;
+    else if (!(fabs(a_new - alpha) > tol))
+      done = 1;
+    alpha = a_new;
+    last0 = t0;
+    last1 = t1;
+  }
+  if (wg == 0 && tid == 0) {
+    st->alpha = alpha;
+    st->alpha_prev = alpha_prev;
+    st->sums[0] = last0;
+    st->sums[1] = last1;
+    st->iters = it;
+    st->done = done;
+  }
+}
+
 __global__ void k_check_state(const effq_fp_state* st, int32_t* err_flag) {
   if (st->done != 1) *err_flag = (st->done == 2) ? 2 : 3;
 }
@@ -478,7 +591,7 @@ int effq_alpha_fixed_point(const float* x, size_t n, int levels, double lo, doub
   return EFFQ_OK;
 }
 
-size_t effq_fp_small_max(void) { return (size_t)1 << 17; }
+size_t effq_fp_small_max(void) { return (size_t)1 << 15; }
 
 int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                            double tol, int max_iter, effq_fp_state* state_dev, void* stream) {
@@ -488,6 +601,35 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
   const double d = (hi - lo) / (double)(levels - 1);
   hipLaunchKernelGGL(k_fp_small, dim3(1), dim3(FPS_T), 0, as_stream(stream), a, b, v_out, n, state_dev, lo, hi, d, tol,
                      max_iter);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+size_t effq_fp_coop_max(void) { return (size_t)FPC_SLICE * FPC_MAXG; }
+
+int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                          double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream) {
+  EFFQ_CHECK_ARG(a && state_dev && ws && n > 0 && levels >= 2 && hi > lo && max_iter > 0);
+  EFFQ_CHECK_ARG(n <= effq_fp_coop_max());
+  EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
+  const double d = (hi - lo) / (double)(levels - 1);
+  int G = (int)((n + FPC_SLICE - 1) / FPC_SLICE);
+  if (G < 1) G = 1;
+  const size_t per = (n + G - 1) / G;
+  const size_t lds = per * sizeof(float);
+  // workspace: reuse the reduction workspace: partials [2][64][2] doubles at its start, counter after them
+  double* partials = reinterpret_cast<double*>(ws);
+  unsigned int* counter = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(ws) + 2 * FPC_MAXG * 2 * sizeof(double));
+  hipStream_t st = as_stream(stream);
+  EFFQ_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), st));
+  static bool attr_set = false;
+  if (!attr_set) {
+    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fp_coop), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(FPC_SLICE * sizeof(float))));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_fp_coop, dim3(G), dim3(FPC_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol, max_iter,
+                     partials, counter);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

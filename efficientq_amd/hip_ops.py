@@ -14,6 +14,8 @@ from . import _lib
 from ._lib import Geom, check
 
 ADMM_TOL = 1e-5   # layer_helper.py:55
+import os as _os
+COOP_FIXED_POINT = _os.environ.get("EFFQ_COOP_FP", "1") != "0"
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -188,6 +190,11 @@ class HipOps:
         if n <= self.lib.effq_fp_small_max():
             check(self.lib.effq_fixed_point_small(_ptr(wstar), _ptr(dual), _ptr(v), n, levels, -1.0, 1.0, ADMM_TOL,
                                                   100 * levels, _ptr(state), self.stream), "effq_fixed_point_small")
+            return None
+        if n <= self.lib.effq_fp_coop_max() and COOP_FIXED_POINT:
+            check(self.lib.effq_fixed_point_coop(_ptr(wstar), _ptr(dual), _ptr(v), n, levels, -1.0, 1.0, ADMM_TOL,
+                                                 100 * levels, _ptr(state), _ptr(self._red_ws), self.stream),
+                  "effq_fixed_point_coop")
             return None
         self.admm_presum(wstar, dual, v)
         _, it, _ = self.fit_scale(v, levels, -1.0, 1.0, guess_iters=guess, state=state)

@@ -341,3 +341,25 @@ def test_exact_int_conv_step_equals_fp32_path(ops, c1, c2, La, Lw, sp):
     sq8b = torch.zeros(2, dtype=torch.float64, device="cuda:0")
     ops.conv_step_i8(xidx, Gq, b, geom, y, alpha_act, La, st_w, Lw, sq8b)
     assert sq8b.cpu().tolist() == s8
+
+
+@pytest.mark.parametrize("n,L", [(40000, 4), (110592, 4), (442368, 16), (1769472, 4), (300001, 256)])
+def test_cooperative_weight_fixed_point_matches_oracle(ops, n, L):
+    """effq_fixed_point_coop (several workgroups, grid barrier per iteration): same alpha / iteration count as the
+    fp64 oracle, v = w* + dual formed on the fly, identical on repetition (deterministic combination order)."""
+    gen = torch.Generator().manual_seed(n + L)
+    w = torch.randn(n, generator=gen) * 0.05
+    du = torch.randn(n, generator=gen) * 0.005
+    assert ops.lib.effq_fp_small_max() < n <= ops.lib.effq_fp_coop_max()
+    v = torch.empty(n, device="cuda:0")
+    st = ops.new_fp_state()
+    assert ops.weight_fixed_point(dev(w), dev(du), v, L, st) is None          # no host round trip
+    alpha, iters, done = ops.read_fp_state(st)
+    vsum = w + du
+    fit = O.fit_scale(vsum, L, -1, 1)
+    assert torch.equal(v.cpu(), vsum)
+    assert done == 1 and iters == fit.iters, (done, iters, fit.iters)
+    assert abs(alpha - fit.alpha) <= 1e-11 * fit.alpha
+    st2 = ops.new_fp_state()
+    ops.weight_fixed_point(dev(w), dev(du), v, L, st2)
+    assert ops.read_fp_state(st2) == (alpha, iters, done)
