@@ -225,6 +225,7 @@ __global__ __launch_bounds__(TPB) void k_fp_iter(const float* __restrict__ x, si
 // 1024-thread workgroup computes mean|v|, then iterates statistics + update until convergence or the
 // cap, all on chip.  v = a + b2 (b2 may be NULL) is formed on the fly and optionally stored to v_out.
 constexpr int FPS_T = 1024;
+constexpr int FPS_PER = 32;     // elements per thread held in registers: n <= 32768
 __global__ __launch_bounds__(FPS_T) void k_fp_small(const float* __restrict__ a, const float* __restrict__ b2,
                                                     float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
                                                     double hi, double d, double tol, int max_iter) {
@@ -232,10 +233,18 @@ __global__ __launch_bounds__(FPS_T) void k_fp_small(const float* __restrict__ a,
   __shared__ double s_alpha;
   __shared__ int s_done;
   const int tid = threadIdx.x;
+  const int kmax = (int)((n + FPS_T - 1) / FPS_T);   // live register slots (uniform)
+  float vr[FPS_PER];
   double acc[2] = {0.0, 0.0};
-  for (size_t i = tid; i < n; i += FPS_T) {
-    const float v = (b2 != nullptr) ? (a[i] + b2[i]) : a[i];
-    if (v_out != nullptr) v_out[i] = v;
+#pragma unroll
+  for (int k = 0; k < FPS_PER; ++k) {
+    const size_t i = (size_t)tid + (size_t)k * FPS_T;
+    float v = 0.0f;
+    if (k < kmax && i < n) {
+      v = (b2 != nullptr) ? (a[i] + b2[i]) : a[i];
+      if (v_out != nullptr) v_out[i] = v;
+    }
+    vr[k] = v;
     acc[0] += fabs((double)v);
   }
   block_sum<2>(acc, smem);
@@ -244,18 +253,21 @@ __global__ __launch_bounds__(FPS_T) void k_fp_small(const float* __restrict__ a,
     s_done = 0;
   }
   __syncthreads();
-  const float* src = (v_out != nullptr) ? v_out : a;   // when v_out is NULL, b2 must be NULL as well
   double alpha = s_alpha, alpha_prev = -999.0;
   int it = 0, done = 0;
   while (!done) {
     acc[0] = acc[1] = 0.0;
     const double ralpha = 1.0 / alpha, rd = 1.0 / d;
-    for (size_t i = tid; i < n; i += FPS_T) {
-      const double v = (double)src[i];
-      double r;
-      const double bq = disc64_fast(v, alpha, ralpha, lo, hi, d, rd, &r);
-      acc[0] += bq * v;
-      acc[1] += bq * bq;
+#pragma unroll
+    for (int k = 0; k < FPS_PER; ++k) {
+      const size_t i = (size_t)tid + (size_t)k * FPS_T;
+      if (k < kmax && i < n) {
+        const double v = (double)vr[k];
+        double r;
+        const double bq = disc64_fast(v, alpha, ralpha, lo, hi, d, rd, &r);
+        acc[0] += bq * v;
+        acc[1] += bq * bq;
+      }
     }
     block_sum<2>(acc, smem);
     if (tid == 0) {
@@ -284,7 +296,6 @@ __global__ __launch_bounds__(FPS_T) void k_fp_small(const float* __restrict__ a,
     st->done = done;
   }
 }
-
 
 // ---- cooperative whole-fixed-point kernel for larger tensors --------------------------------------
 // G <= 64 workgroups of 1024 threads, one per CU, each owning a contiguous slice of v that stays in LDS for
