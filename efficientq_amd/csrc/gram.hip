@@ -46,7 +46,7 @@ struct VoxInfo {
 // so that with C1 % 4 == 0 and C2 % 4 == 0 every cell is either 4 channels of one tap (one 16-byte
 // load of x), 4 channels of y, or the ones/padding cell.
 struct RowGroup {
-  int kind;        // 0: x cell (kd,kh,kw,c0)   1: y cell (c0)   2: mixed, decode per row   3: padding
+  int kind;        // 0: x cell (kd,kh,kw,c0)  1: y cell (c0)  2: mixed, decode per row  3: padding  4: ones cell
   int kd, kh, kw, c0;
   int r0;
 };
@@ -86,6 +86,7 @@ __device__ __forceinline__ float4 gram_fetch_cell(const GramParams& p, const Row
 
 constexpr int GT = 512;   // threads: 8 waves = 4 row sub-tiles x 2 column halves
 
+template <bool VEC>
 __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
   // double-buffered panels: chunk c+1 is written while chunk c is still being consumed (one barrier per chunk)
   __shared__ __attribute__((aligned(16))) float panI[2][KC * PS];
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
 
   // staging role: cell column g (rows 4g..4g+3 of each 128-row panel), voxels vsub and vsub+16 of a chunk
   const int g = tid & 31, vsub = tid >> 5;
-  const bool vec = (p.C1 & 3) == 0 && (p.C2 & 3) == 0;
+  constexpr bool vec = VEC;
   auto make_group = [&](int r0) {
     RowGroup q;
     q.r0 = r0;
@@ -124,6 +125,10 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
     } else if (vec && r0 >= p.RX && r0 + 3 < p.RX + p.C2) {
       q.kind = 1;
       q.c0 = r0 - p.RX;
+    } else if (vec && p.hb && r0 == p.RX + p.C2) {
+      q.kind = 4;
+    } else if (vec && r0 > p.RX + p.C2) {
+      q.kind = 3;
     } else {
       q.kind = 2;
     }
@@ -135,39 +140,59 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
   unsigned v_end = v_begin + (unsigned)p.vox_per_split;
   if (v_end > (unsigned)p.V) v_end = (unsigned)p.V;
 
-  auto vox_info = [&](unsigned v) {
-    VoxInfo vi;
-    if (v < v_end) {
-      unsigned t = v;
-      const int ow = (int)(t % (unsigned)p.OW);
-      t /= (unsigned)p.OW;
-      const int oh = (int)(t % (unsigned)p.OH);
-      t /= (unsigned)p.OH;
-      const int od = (int)(t % (unsigned)p.OD);
-      vi.n = (int)(t / (unsigned)p.OD);
+  // One staged cell, BRANCH-FREE on the vectorised path: the 16-byte load is unconditional on a clamped (always
+  // valid) address and masked afterwards.  A load under a runtime branch makes hipcc wait for it inside the
+  // branch (vmcnt(0)), which serialised the whole prefetch in front of the MFMA loop (cdna_hip_programming.md,
+  // projection-GEMM trap 4c); with straight-line code the loads fly under the MFMAs.
+  // returns the RAW loaded cell; `code` says what to do with it when it is stored to LDS (0 zero, 1 keep,
+  // 2 ones cell): nothing touches the loaded registers before the MFMA loop, so no wait is placed there
+  auto fetch_cell = [&](const RowGroup& q, unsigned v, int& code) -> float4 {
+    const bool vvalid = v < v_end;
+    const unsigned cv = vvalid ? v : v_begin;
+    unsigned t = cv;
+    const int ow = (int)(t % (unsigned)p.OW);
+    t /= (unsigned)p.OW;
+    const int oh = (int)(t % (unsigned)p.OH);
+    t /= (unsigned)p.OH;
+    const int od = (int)(t % (unsigned)p.OD);
+    const int n = (int)(t / (unsigned)p.OD);
+    const int id = od * p.SD - p.PD + q.kd, ih = oh * p.SH - p.PH + q.kh, iw = ow * p.SW - p.PW + q.kw;
+    const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+    if (VEC) {
+      const int cd = min(max(id, 0), p.D - 1), ch = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
+      const size_t xoff = ((((size_t)n * p.D + cd) * p.H + ch) * p.W + cw) * p.C1 + q.c0;
+      const size_t yoff = (size_t)cv * p.C2 + ((q.kind == 1) ? q.c0 : 0);
+      const float* src = (q.kind == 0) ? (p.x + xoff) : (p.y + yoff);
+      const float4 val = *reinterpret_cast<const float4*>(src);
+      const bool ok = vvalid && ((q.kind == 0 && inb) || q.kind == 1);
+      code = ok ? 1 : ((q.kind == 4 && vvalid) ? 2 : 0);
+      return val;
+    } else {
+      code = 1;
+      VoxInfo vi;
+      vi.n = vvalid ? n : -1;
       vi.id0 = od * p.SD - p.PD;
       vi.ih0 = oh * p.SH - p.PH;
       vi.iw0 = ow * p.SW - p.PW;
-    } else {
-      vi.n = -1;
-      vi.id0 = vi.ih0 = vi.iw0 = 0;
+      return gram_fetch_cell(p, q, vi, v);
     }
-    return vi;
   };
 
   float4 rI[2], rJ[2];
-  float ratt = 0.0f;
+  int cI[2], cJ[2];
+  float ratt = 1.0f;
+  bool ratt_ok = false;
   auto prefetch = [&](unsigned v0) {
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const unsigned v = v0 + vsub + 16 * ps;
-      const VoxInfo vi = vox_info(v);
-      rI[ps] = gram_fetch_cell(p, gI, vi, v);
-      if (!diag) rJ[ps] = gram_fetch_cell(p, gJ, vi, v);
+      rI[ps] = fetch_cell(gI, v, cI[ps]);
+      if (!diag) rJ[ps] = fetch_cell(gJ, v, cJ[ps]);
     }
-    if (tid < KC) {
-      const unsigned v = v0 + tid;
-      ratt = (v < v_end) ? ((p.att != nullptr) ? p.att[v] : 1.0f) : 0.0f;
+    {
+      const unsigned v = v0 + (tid & (KC - 1));
+      ratt_ok = v < v_end;                               // masked at the LDS store, like the cells
+      if (p.att != nullptr) ratt = p.att[ratt_ok ? v : v_begin];
     }
   };
 
@@ -189,14 +214,20 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
   // sub-tiles made only of padding rows (>= E) are skipped: wave-uniform predicates
   const bool rows_live = I * MB + wi * 32 < p.E;
   const bool col_live[2] = {J * MB + (2 * wjh + 0) * 32 < p.E, J * MB + (2 * wjh + 1) * 32 < p.E};
+  auto masked = [](const float4& raw, int code) {
+    float4 o = raw;
+    if (code == 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (code == 2) o = make_float4(1.f, 0.f, 0.f, 0.f);
+    return o;
+  };
   auto stage = [&](int buf) {
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const int vv = vsub + 16 * ps;
-      *reinterpret_cast<float4*>(&panI[buf][vv * PS + 4 * g]) = rI[ps];
-      if (!diag) *reinterpret_cast<float4*>(&panJ[buf][vv * PS + 4 * g]) = rJ[ps];
+      *reinterpret_cast<float4*>(&panI[buf][vv * PS + 4 * g]) = masked(rI[ps], cI[ps]);
+      if (!diag) *reinterpret_cast<float4*>(&panJ[buf][vv * PS + 4 * g]) = masked(rJ[ps], cJ[ps]);
     }
-    if (tid < KC) att_s[buf][tid] = ratt;
+    if (tid < KC) att_s[buf][tid] = ratt_ok ? ratt : 0.0f;
   };
 
   int buf = 0;
@@ -207,7 +238,8 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
   __syncthreads();
   for (unsigned v0 = v_begin; v0 < v_end; v0 += KC, buf ^= 1) {
     const bool more = v0 + KC < v_end;
-    if (more && p.debug != 2) prefetch(v0 + KC);  // lands in registers under the MFMAs below
+    if (p.debug != 2) prefetch(more ? v0 + KC : v0);   // unconditional (the last chunk re-reads itself): lands
+                                                        // in registers under the MFMAs below
     if (rows_live && col_live[0] && p.debug != 1) {
       const float* pi = panI[buf];
       const float* pj = diag ? panI[buf] : panJ[buf];
@@ -384,7 +416,10 @@ int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc
   p.y = y_ndhwc;
   p.slabs = reinterpret_cast<double*>(ws);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(k_gram, dim3((unsigned)p.npairs, (unsigned)p.nsplit), dim3(GT), 0, st, p);
+  if ((p.C1 & 3) == 0 && (p.C2 & 3) == 0)
+    hipLaunchKernelGGL(k_gram<true>, dim3((unsigned)p.npairs, (unsigned)p.nsplit), dim3(GT), 0, st, p);
+  else
+    hipLaunchKernelGGL(k_gram<false>, dim3((unsigned)p.npairs, (unsigned)p.nsplit), dim3(GT), 0, st, p);
   EFFQ_LAUNCH_CHECK();
   const int n = p.RX + p.hb;
   size_t tot = (size_t)n * n + (size_t)p.C2 * n;
