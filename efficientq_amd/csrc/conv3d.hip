@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ G
 // overlap the arithmetic.  Weights come straight from L2 (one 16-byte load per lane per 4 MFMAs).
 constexpr int G_MAXH = 12;   // halo 16-byte loads per thread per slab (plan guarantees nhalo*cslab/4 <= 3072)
 
-template <int NT>
+template <int NT, bool VEC, bool HAS_Y>
 __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ double red_smem[2 * 16];
@@ -104,47 +104,48 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
   const int HH = p.HH, HW = p.HW, CS = p.CS;
   const int upv = p.cslab >> 2;
   const int nh4 = p.nhalo * upv;
-  const bool vec_ok = (p.C1 & 3) == 0;
-  auto load_halo = [&](const Tile& tl, int slab, float4(&hreg)[G_MAXH]) {
+  // Prefetch loads are UNCONDITIONAL on clamped (always valid) addresses; validity bits are applied when the
+  // registers are stored to LDS.  A load under a runtime branch makes hipcc wait for it inside the branch
+  // (vmcnt(0)), which serialised the whole prefetch in front of the MFMA loop.
+  auto load_halo = [&](const Tile& tl, int slab, float4(&hreg)[G_MAXH], unsigned& hmask) {
     const int id0 = tl.od0 * p.SD - p.PD, ih0 = tl.oh0 * p.SH - p.PH, iw0 = tl.ow0 * p.SW - p.PW;
+    hmask = 0u;
 #pragma unroll
     for (int k = 0; k < G_MAXH; ++k) {
-      const int u = tid + k * 256;
-      hreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (u < nh4) {
-        const int vox = u / upv, c4 = u - vox * upv;
-        const int hw = vox % HW;
-        const int t2 = vox / HW;
-        const int hh = t2 % HH, hd = t2 / HH;
-        const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-        const int c = slab * p.cslab + c4 * 4;
-        if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && c < p.C1 && p.debug != 2) {
-          const float* src = p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 + c;
-          if (vec_ok) {
-            hreg[k] = *reinterpret_cast<const float4*>(src);
-          } else {
-            hreg[k].x = src[0];
-            if (c + 1 < p.C1) hreg[k].y = src[1];
-            if (c + 2 < p.C1) hreg[k].z = src[2];
-            if (c + 3 < p.C1) hreg[k].w = src[3];
-          }
-        }
+      int u = tid + k * 256;
+      const bool live = u < nh4;
+      u = live ? u : 0;
+      const int vox = u / upv, c4 = u - vox * upv;
+      const int hw = vox % HW;
+      const int t2 = vox / HW;
+      const int hh = t2 % HH, hd = t2 / HH;
+      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+      const int c = slab * p.cslab + c4 * 4;
+      const bool ok = live && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && c < p.C1;
+      const int cd = min(max(id, 0), p.D - 1), chh = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
+      const float* vp = p.x + ((((size_t)tl.n * p.D + cd) * p.H + chh) * p.W + cw) * p.C1;
+      if (VEC) {
+        hreg[k] = *reinterpret_cast<const float4*>(vp + min(c, p.C1 - 4));
+      } else {
+        hreg[k].x = vp[min(c + 0, p.C1 - 1)];
+        hreg[k].y = vp[min(c + 1, p.C1 - 1)];
+        hreg[k].z = vp[min(c + 2, p.C1 - 1)];
+        hreg[k].w = vp[min(c + 3, p.C1 - 1)];
       }
+      hmask |= (ok ? 1u : 0u) << k;
     }
   };
   // targets in accumulator layout: lane (li,lh), register r <-> voxel (r&3)+8*(r>>2)+4*lh of d-plane wid
   auto load_y = [&](const Tile& tl, float(&yv)[NT][16]) {
-    const int od = tl.od0 + wid;
+    const int od = min(tl.od0 + wid, p.OD - 1);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int ch = ch0 + nt * 32 + li;
+      const int ch = min(ch0 + nt * 32 + li, p.C2 - 1);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int oh = tl.oh0 + (i >> 3), ow = tl.ow0 + (i & 7);
-        yv[nt][r] = 0.0f;
-        if (ch < p.C2 && od < p.OD && oh < p.OH && ow < p.OW && p.debug != 3)
-          yv[nt][r] = p.y[((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 + ch];
+        const int oh = min(tl.oh0 + (i >> 3), p.OH - 1), ow = min(tl.ow0 + (i & 7), p.OW - 1);
+        yv[nt][r] = p.y[((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 + ch];   // masked in the epilogue
       }
     }
   };
@@ -158,10 +159,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
   const int hv = ((wid * p.SD) * HH + (li >> 3) * p.SH) * HW + (li & 7) * p.SW;
   float alpha = 1.0f;
   if (p.act_on) alpha = *p.act_alpha;
-  const bool has_y = p.y != nullptr;
+  constexpr bool has_y = HAS_Y;
   double l0 = 0.0, l1 = 0.0;
 
   float4 hreg[G_MAXH];
+  unsigned hmask = 0u;
   float ynext[NT][16], ycur[NT][16];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
     for (int r = 0; r < 16; ++r) ycur[nt][r] = ynext[nt][r] = 0.0f;
   if (nstage > 0) {
     const Tile t0 = decode(t_begin);
-    load_halo(t0, 0, hreg);
-    if (has_y) load_y(t0, ynext);
+    load_halo(t0, 0, hreg, hmask);
+    if (HAS_Y) load_y(t0, ynext);
   }
 
   int tile = t_begin, slab = 0;
@@ -179,8 +181,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
 #pragma unroll
     for (int q = 0; q < G_MAXH; ++q) {
       const int u = tid + q * 256;
-      if (u < nh4 && p.debug != 4) {
-        float4 v = hreg[q];
+      if (u < nh4) {
+        float4 v = ((hmask >> q) & 1u) ? hreg[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!VEC) {      // components beyond C1 of a partial channel quad
+          const int c = slab * p.cslab + (u % upv) * 4;
+          if (c + 1 >= p.C1) v.y = 0.f;
+          if (c + 2 >= p.C1) v.z = 0.f;
+          if (c + 3 >= p.C1) v.w = 0.f;
+        }
         if (p.act_on) {
           v.x = act_qd(v.x, alpha, p.act_d);
           v.y = act_qd(v.y, alpha, p.act_d);
@@ -204,10 +212,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
       slab_n = 0;
       tile_n = tile + 1;
     }
-    if (k + 1 < nstage) {
-      const Tile tn = decode(tile_n);
-      load_halo(tn, slab_n, hreg);
-      if (slab_n == 0 && has_y) load_y(tn, ynext);
+    {
+      // unconditional: the last stage re-fetches itself (never consumed)
+      const bool more = k + 1 < nstage;
+      const Tile tn = decode(more ? tile_n : tile);
+      const int sl = more ? slab_n : slab;
+      load_halo(tn, sl, hreg, hmask);
+      if (HAS_Y) load_y(tn, ynext);       // consumed only after a slab-0 stage (ycur = ynext there)
     }
 
     // flattened (tap, 8-channel chunk) loop with the NEXT step's operands (LDS A fragment, L2 B fragments)
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
 // flight ahead of its 16*NT MFMAs.
 constexpr int F_HD = TD + 2, F_HH = TH + 2, F_HW = TW + 2, F_NH = F_HD * F_HH * F_HW, F_CS = 36;
 
-template <int NT>
+template <int NT, bool HAS_Y>
 __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
   // Persistent form: gridDim.x workgroups (<= 2 per CU) each walk a contiguous run of spatial tiles.
   // The global loads of stage k+1 (halo slab, and the targets of the next tile) are issued right
@@ -344,20 +355,26 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
     r.n = t / p.tiles_d;
     return r;
   };
-  auto load_halo = [&](const Tile& tl, int slab, float4(&hreg)[NHL]) {
+  // prefetch loads are unconditional on clamped addresses (a load under a runtime branch is waited for inside
+  // the branch and would serialise the prefetch); validity is applied at the LDS store / in the epilogue
+  auto load_halo = [&](const Tile& tl, int slab, float4(&hreg)[NHL], unsigned& hmask) {
     const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
+    hmask = 0u;
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
-      const int u = tid + k * 256;
+      int u = tid + k * 256;
+      const bool live = u < F_NH * 8;
+      u = live ? u : 0;
       const int vox = u >> 3, c4 = u & 7;
       const int hw = vox % F_HW;
       const int t2 = vox / F_HW;
       const int hh = t2 % F_HH, hd = t2 / F_HH;
       const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-      hreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (u < F_NH * 8 && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && p.debug != 2)
-        hreg[k] = *reinterpret_cast<const float4*>(p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 +
-                                                   slab * 32 + c4 * 4);
+      const bool ok = live && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+      const int cd = min(max(id, 0), p.D - 1), chh = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
+      hreg[k] = *reinterpret_cast<const float4*>(p.x + ((((size_t)tl.n * p.D + cd) * p.H + chh) * p.W + cw) * p.C1 +
+                                                 slab * 32 + c4 * 4);
+      hmask |= (ok ? 1u : 0u) << k;
     }
   };
   auto load_y = [&](const Tile& tl, float4(&yv)[NCELL]) {
@@ -365,11 +382,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
     for (int k = 0; k < NCELL; ++k) {
       const int u = tid + k * 256;
       const int vox = u / CPV;
-      const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
-      yv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (od < p.OD && oh < p.OH && ow < p.OW && p.debug != 3)
-        yv[k] = *reinterpret_cast<const float4*>(p.y + ((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 +
-                                                 ch0 + (u % CPV) * 4);
+      const int od = min(tl.od0 + (vox >> 5), p.OD - 1), oh = min(tl.oh0 + ((vox >> 3) & 3), p.OH - 1),
+                ow = min(tl.ow0 + (vox & 7), p.OW - 1);
+      yv[k] = *reinterpret_cast<const float4*>(p.y + ((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 +
+                                               ch0 + (u % CPV) * 4);
     }
   };
 
@@ -385,16 +401,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
   const int c4q = p.c1p >> 2;
   const int wq = tid >> 5, wj = tid & 31;      // this thread's slot of the per-tap weight block
   const size_t wtap = (size_t)c4q * p.c2p;     // float4 stride between taps
-  const bool has_y = p.y != nullptr;
+  constexpr bool has_y = HAS_Y;
   double l0 = 0.0, l1 = 0.0;
 
   float4 hreg[NHL], ynext[NCELL], ycur[NCELL];
+  unsigned hmask = 0u;
 #pragma unroll
   for (int k = 0; k < NCELL; ++k) ycur[k] = ynext[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (nstage > 0) {
     const Tile t0 = decode(t_begin);
-    load_halo(t0, 0, hreg);
-    if (has_y) load_y(t0, ynext);
+    load_halo(t0, 0, hreg, hmask);
+    if (HAS_Y) load_y(t0, ynext);
   }
 
   int tile = t_begin, slab = 0;
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
     for (int q = 0; q < NHL; ++q) {
       const int u = tid + q * 256;
       if (u < F_NH * 8) {
-        float4 v = hreg[q];
+        float4 v = ((hmask >> q) & 1u) ? hreg[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.act_on) {
           v.x = act_qd(v.x, alpha, p.act_d);
           v.y = act_qd(v.y, alpha, p.act_d);
@@ -432,10 +449,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
       slab_n = 0;
       tile_n = tile + 1;
     }
-    if (k + 1 < nstage) {
-      const Tile tn = decode(tile_n);
-      load_halo(tn, slab_n, hreg);
-      if (slab_n == 0 && has_y) load_y(tn, ynext);
+    {
+      // unconditional: the last stage re-fetches itself (never consumed)
+      const bool more = k + 1 < nstage;
+      const Tile tn = decode(more ? tile_n : tile);
+      load_halo(tn, more ? slab_n : slab, hreg, hmask);
+      if (HAS_Y) load_y(tn, ynext);       // consumed only after a slab-0 stage (ycur = ynext there)
     }
 
     const int ntap = (p.debug == 1) ? 0 : 27;
@@ -672,26 +691,34 @@ int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* 
     EFFQ_LAUNCH_CHECK();
   }
   const size_t lds = pl.lds_bytes;
-#define EFFQ_CONV_LAUNCH(NTV)                                                                                  \
+  const bool has_y = y_fp != nullptr, vec = (p.C1 & 3) == 0;
+#define EFFQ_LAUNCH_K(KERN)                                                                                    \
   do {                                                                                                         \
     if (lds > 64 * 1024)                                                                                       \
-      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d<NTV>),                              \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
-    hipLaunchKernelGGL(k_conv3d<NTV>, pl.grid, dim3(256), lds, st, p);                                         \
+      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)lds));                                                                 \
+    hipLaunchKernelGGL(KERN, pl.grid, dim3(256), lds, st, p);                                                  \
   } while (0)
   if (pl.fast) {
     if (pl.nt == 2) {
-      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_k3<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_conv3d_k3<2>, pl.grid, dim3(256), lds, st, p);
+      if (has_y) EFFQ_LAUNCH_K((k_conv3d_k3<2, true>)); else EFFQ_LAUNCH_K((k_conv3d_k3<2, false>));
     } else {
-      hipLaunchKernelGGL(k_conv3d_k3<1>, pl.grid, dim3(256), lds, st, p);
+      if (has_y) EFFQ_LAUNCH_K((k_conv3d_k3<1, true>)); else EFFQ_LAUNCH_K((k_conv3d_k3<1, false>));
     }
-  } else if (pl.nt == 2)
-    EFFQ_CONV_LAUNCH(2);
-  else
-    EFFQ_CONV_LAUNCH(1);
-#undef EFFQ_CONV_LAUNCH
+  } else if (pl.nt == 2) {
+    if (vec) {
+      if (has_y) EFFQ_LAUNCH_K((k_conv3d<2, true, true>)); else EFFQ_LAUNCH_K((k_conv3d<2, true, false>));
+    } else {
+      if (has_y) EFFQ_LAUNCH_K((k_conv3d<2, false, true>)); else EFFQ_LAUNCH_K((k_conv3d<2, false, false>));
+    }
+  } else {
+    if (vec) {
+      if (has_y) EFFQ_LAUNCH_K((k_conv3d<1, true, true>)); else EFFQ_LAUNCH_K((k_conv3d<1, true, false>));
+    } else {
+      if (has_y) EFFQ_LAUNCH_K((k_conv3d<1, false, true>)); else EFFQ_LAUNCH_K((k_conv3d<1, false, false>));
+    }
+  }
+#undef EFFQ_LAUNCH_K
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }
