@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void k_gj_diag(const double* __restrict__ A, i
   double reg[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) reg[j] = A[(size_t)(kb + lane) * npad + kb + wid * 16 + j];
-#pragma unroll 1
-  for (int p = 0; p < NBK; ++p) {
+#pragma unroll
+  for (int p = 0; p < NBK; ++p) {      // fully unrolled: pivot column / lane selectors become immediates
     const int par = p & 1, wp = p >> 4, jp = p & 15;
     if (wid == wp) {
       double cp = reg[0];
