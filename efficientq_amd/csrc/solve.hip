@@ -6,12 +6,14 @@
 // only when rho does (5 values per layer), so the inverse is formed once per rho in fp64 by a
 // blocked in-place Gauss-Jordan sweep (no pivoting needed for SPD) whose bulk is a rank-64 fp64
 // MFMA update (v_mfma_f64_16x16x4_f64), then rounded once to fp32.
+#include <cstdlib>
 #include "common.h"
 
 namespace effq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -271,14 +273,15 @@ __global__ __launch_bounds__(256) void k_build_b(const float* __restrict__ B0, c
 // What = Bm * Ainv on the f32 matrix cores.  Ainv is exactly symmetric, so What[r][c] = sum_k Bm[r][k] *
 // Ainv[c][k]: BOTH operands are read along K (contiguous, 16-byte loads), staged as [row][32+4] tiles in
 // LDS (conflict-free ds_read_b128, 4 MFMAs per pair of reads) with the next K tile prefetched into
-// registers under the MFMAs of the current one.  Workgroup tile = (32*WM) x (32*WN*NTN), 4 waves.
+// registers under the MFMAs of the current one.  Wave tile = (32*MT) x (32*NTN); workgroup tile =
+// (32*MT*WM) x (32*NTN*WN), 4 waves.
 constexpr int PBK = 32, PLD = PBK + 4;
 
-template <int WM, int WN, int NTN>
+template <int MT, int WM, int WN, int NTN>
 __global__ __launch_bounds__(256) void k_prox_gemm(const float* __restrict__ Bm, int ldb, const float* __restrict__ Ainv,
                                                    int lda, int n, int c2, int has_bias, float* __restrict__ wstar,
-                                                   float* __restrict__ bstar) {
-  constexpr int BM = 32 * WM, BN = 32 * WN * NTN;
+                                                   float* __restrict__ bstar, float* __restrict__ part, int ldp) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * WN * NTN;
   constexpr int NA = BM * 8 / 256, NB = BN * 8 / 256;   // 16-byte loads per thread per K tile
   static_assert(WM * WN == 4 && NA >= 1 && NB >= 1, "4 waves");
   __shared__ __attribute__((aligned(16))) float As[BM * PLD];
@@ -288,73 +291,151 @@ __global__ __launch_bounds__(256) void k_prox_gemm(const float* __restrict__ Bm,
   const int wm = wid / WN, wn = wid % WN;
   const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
 
-  f32x16 acc[NTN];
+  f32x16 acc[MT][NTN];
 #pragma unroll
-  for (int t = 0; t < NTN; ++t)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
 
-  float4 ra[NA], rb[NB];
-  auto fetch = [&](int k0) {
+  // The prefetch is written out twice (prologue and loop) rather than as a lambda over ra/rb: captured by
+  // reference the arrays stay in scratch memory and every prefetch is waited for and spilled on the spot.
+  // Columns >= n are clamped (their outputs are dropped below): an unconditional load keeps the prefetch
+  // asynchronous, a branch around it makes hipcc wait for it inside the branch.
+  f32x4 ra[NA], rb[NB];
+  const float* pa[NA];
+  const float* pb[NB];
 #pragma unroll
-    for (int q = 0; q < NA; ++q) {
-      const int u = tid + q * 256, r = u >> 3, c4 = u & 7;
-      ra[q] = *reinterpret_cast<const float4*>(Bm + (size_t)(row0 + r) * ldb + k0 + c4 * 4);   // Bm is zero padded
-    }
+  for (int q = 0; q < NA; ++q) {
+    const int u = tid + q * 256, r = u >> 3, c4 = u & 7;
+    pa[q] = Bm + (size_t)(row0 + r) * ldb + c4 * 4;   // Bm is zero padded
+  }
 #pragma unroll
-    for (int q = 0; q < NB; ++q) {
-      const int u = tid + q * 256, r = u >> 3, c4 = u & 7;
-      const int col = col0 + r;
-      rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (col < n) rb[q] = *reinterpret_cast<const float4*>(Ainv + (size_t)col * lda + k0 + c4 * 4);  // lda padded
-    }
-  };
-  const int nk = ldb / PBK;   // ldb is a multiple of 32
-  fetch(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int q = 0; q < NB; ++q) {
+    const int u = tid + q * 256, r = u >> 3, c4 = u & 7;
+    pb[q] = Ainv + (size_t)min(col0 + r, n - 1) * lda + c4 * 4;   // lda padded
+  }
+#define EFFQ_PROX_FETCH(k0)                                                         \
+  {                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < NA; ++q)                                  \
+        ra[q] = *reinterpret_cast<const f32x4*>(pa[q] + (k0));                      \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q)                                  \
+        rb[q] = *reinterpret_cast<const f32x4*>(pb[q] + (k0));                      \
+  }
+  // split K: slice z of gridDim.z takes K tiles [kt0, kt1); with more than one slice the partial tile goes
+  // to part[z] and k_prox_reduce adds the slices in a fixed order
+  const int nkt = ldb / PBK;   // ldb is a multiple of 32
+  const int kt0 = (int)(((long long)nkt * blockIdx.z) / gridDim.z);
+  const int nk = (int)(((long long)nkt * (blockIdx.z + 1)) / gridDim.z);
+  EFFQ_PROX_FETCH(kt0 * PBK)
+  for (int kt = kt0; kt < nk; ++kt) {
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const int u = tid + q * 256;
-      *reinterpret_cast<float4*>(&As[(u >> 3) * PLD + (u & 7) * 4]) = ra[q];
+      *reinterpret_cast<f32x4*>(&As[(u >> 3) * PLD + (u & 7) * 4]) = ra[q];
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       const int u = tid + q * 256;
-      *reinterpret_cast<float4*>(&Bs[(u >> 3) * PLD + (u & 7) * 4]) = rb[q];
+      *reinterpret_cast<f32x4*>(&Bs[(u >> 3) * PLD + (u & 7) * 4]) = rb[q];
     }
     __syncthreads();
-    if (kt + 1 < nk) fetch((kt + 1) * PBK);
+    EFFQ_PROX_FETCH(min(kt + 1, nk - 1) * PBK)   // unconditional: the last one is a harmless re-read
+    __builtin_amdgcn_sched_barrier(0);           // keep the loads ahead of the MFMAs they hide under
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 a = *reinterpret_cast<const float4*>(&As[(wm * 32 + li) * PLD + q * 8 + 4 * lh]);
+      f32x4 a[MT], b[NTN];
 #pragma unroll
-      for (int t = 0; t < NTN; ++t) {
-        const float4 b = *reinterpret_cast<const float4*>(&Bs[((wn * NTN + t) * 32 + li) * PLD + q * 8 + 4 * lh]);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
-      }
+      for (int m = 0; m < MT; ++m)
+        a[m] = *reinterpret_cast<const f32x4*>(&As[((wm * MT + m) * 32 + li) * PLD + q * 8 + 4 * lh]);
+#pragma unroll
+      for (int t = 0; t < NTN; ++t)
+        b[t] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NTN + t) * 32 + li) * PLD + q * 8 + 4 * lh]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTN; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][e], b[t][e], acc[m][t], 0, 0, 0);
     }
   }
+#undef EFFQ_PROX_FETCH
   const int nw = n - has_bias;
+  if (gridDim.z > 1) {
+    float* P = part + (size_t)blockIdx.z * c2 * ldp;
 #pragma unroll
-  for (int t = 0; t < NTN; ++t) {
-    const int col = col0 + (wn * NTN + t) * 32 + li;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row < c2 && col < n) {
-        if (col < nw)
-          wstar[(size_t)row * nw + col] = acc[t][r];
-        else
-          bstar[row] = acc[t][r];
+      for (int t = 0; t < NTN; ++t) {
+        const int col = col0 + (wn * NTN + t) * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < c2 && col < n) P[(size_t)row * ldp + col] = acc[m][t][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) {
+      const int col = col0 + (wn * NTN + t) * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < c2 && col < n) {
+          if (col < nw)
+            wstar[(size_t)row * nw + col] = acc[m][t][r];
+          else
+            bstar[row] = acc[m][t][r];
+        }
       }
     }
+}
+
+
+// What = sum_z part[z] in slice order (deterministic), scattered to [wstar | bstar]
+__global__ __launch_bounds__(256) void k_prox_reduce(const float* __restrict__ part, int ldp, int nsplit, int c2, int n,
+                                                     int has_bias, float* __restrict__ wstar, float* __restrict__ bstar) {
+  const size_t tot = (size_t)c2 * ldp, stride = (size_t)gridDim.x * blockDim.x;
+  const int nw = n - has_bias;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) {
+    const int row = (int)(e / ldp), col = (int)(e % ldp);
+    if (col >= n) continue;
+    float v = part[e];
+    for (int z = 1; z < nsplit; ++z) v += part[(size_t)z * tot + e];
+    if (col < nw)
+      wstar[(size_t)row * nw + col] = v;
+    else
+      bstar[row] = v;
   }
 }
 
+// workgroup tile variant and K split of the prox GEMM: ~440 workgroups, >= 6 K tiles per slice (measured
+// best on MI355X for the BraTS sizes: scripts/prof_prox.py with EFFQ_PROX_SPLIT)
+struct ProxPlan { int variant, gx, gy, nsplit, c2p, ldb; };
+static ProxPlan prox_plan(int c2, int n) {
+  ProxPlan p;
+  p.c2p = (c2 > 128) ? round_up(c2, 256) : (c2 > 64) ? 128 : round_up(c2, 32);
+  p.ldb = round_up(n, 32);
+  if (p.c2p >= 256) { p.variant = 0; p.gx = (n + 63) / 64; p.gy = p.c2p / 256; }        // 256x64, waves 64x64
+  else if (p.c2p == 128) { p.variant = 1; p.gx = (n + 63) / 64; p.gy = 1; }             // 128x64, waves 32x64
+  else if (p.c2p == 64) { p.variant = 2; p.gx = (n + 63) / 64; p.gy = 1; }              // 64x64, waves 32x32
+  else { p.variant = 3; p.gx = (n + 127) / 128; p.gy = 1; }                             // 32x128, waves 32x32
+  const int tiles = p.gx * p.gy, nkt = p.ldb / PBK;
+  int s = (440 + tiles - 1) / tiles;
+  if (s > nkt / 6) s = nkt / 6;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  static const int force = getenv("EFFQ_PROX_SPLIT") ? atoi(getenv("EFFQ_PROX_SPLIT")) : 0;   // tuning aid
+  if (force > 0 && force <= nkt) s = force;
+  p.nsplit = s;
+  return p;
+}
 
 }  // namespace effq
 
@@ -420,7 +501,8 @@ int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double et
 
 size_t effq_prox_ws_bytes(int c2, int n) {
   if (c2 <= 0 || n <= 0) return 0;
-  return (size_t)round_up(c2, 128) * round_up(n, 32) * sizeof(float) + 256;
+  const ProxPlan p = prox_plan(c2, n);
+  return ((size_t)p.c2p + (p.nsplit > 1 ? (size_t)p.nsplit * c2 : 0)) * p.ldb * sizeof(float) + 256;
 }
 
 int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
@@ -433,9 +515,11 @@ int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const f
     return EFFQ_ERR_WORKSPACE;
   }
   // rows padded to the workgroup tile, K to the 32-wide K tile (zero filled by k_build_b)
-  const int c2p = (c2 > 64) ? round_up(c2, 128) : round_up(c2, 32), ldb = round_up(n, 32);
+  const ProxPlan pl = prox_plan(c2, n);
+  const int c2p = pl.c2p, ldb = pl.ldb;
   const int lda = effq_ainv_ld(n);
   float* Bm = reinterpret_cast<float*>(ws);
+  float* part = Bm + (size_t)c2p * ldb;
   hipStream_t st = as_stream(stream);
   {
     size_t nb = ((size_t)c2p * ldb + 255) / 256;
@@ -444,18 +528,24 @@ int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const f
                        (float)rho, (float)eta, Bm, ldb, c2p);
     EFFQ_LAUNCH_CHECK();
   }
-  if (c2p >= 128 && ((n + 63) / 64) * (c2p / 128) < 200)   // too few 128x64 tiles to fill 256 CUs: 128x32 tiles
-    hipLaunchKernelGGL((k_prox_gemm<4, 1, 1>), dim3((n + 31) / 32, c2p / 128), dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2,
-                       has_bias ? 1 : 0, wstar, bstar);
-  else if (c2p >= 128)
-    hipLaunchKernelGGL((k_prox_gemm<4, 1, 2>), dim3((n + 63) / 64, c2p / 128), dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2,
-                       has_bias ? 1 : 0, wstar, bstar);
-  else if (c2p == 64)
-    hipLaunchKernelGGL((k_prox_gemm<2, 2, 1>), dim3((n + 63) / 64, 1), dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2,
-                       has_bias ? 1 : 0, wstar, bstar);
-  else
-    hipLaunchKernelGGL((k_prox_gemm<1, 4, 1>), dim3((n + 127) / 128, 1), dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2,
-                       has_bias ? 1 : 0, wstar, bstar);
+  const dim3 grid(pl.gx, pl.gy, pl.nsplit);
+#define EFFQ_PROX_LAUNCH(MT, WM, WN, NTN)                                                                              \
+  hipLaunchKernelGGL((k_prox_gemm<MT, WM, WN, NTN>), grid, dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2, has_bias ? 1 : 0, \
+                     wstar, bstar, part, ldb)
+  switch (pl.variant) {
+    case 0: EFFQ_PROX_LAUNCH(2, 4, 1, 2); break;
+    case 1: EFFQ_PROX_LAUNCH(1, 4, 1, 2); break;
+    case 2: EFFQ_PROX_LAUNCH(1, 2, 2, 1); break;
+    default: EFFQ_PROX_LAUNCH(1, 1, 4, 1); break;
+  }
+#undef EFFQ_PROX_LAUNCH
+  EFFQ_LAUNCH_CHECK();
+  if (pl.nsplit > 1) {
+    size_t nb = ((size_t)c2 * ldb + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_prox_reduce, dim3((unsigned)nb), dim3(256), 0, st, part, ldb, pl.nsplit, c2, n, has_bias ? 1 : 0,
+                       wstar, bstar);
+  }
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }
