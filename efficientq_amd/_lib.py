@@ -44,7 +44,7 @@ class FpState(C.Structure):
 
 FP_STATE_BYTES = C.sizeof(FpState)
 
-_P, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
+_P, _SZ, _I, _F, _D, _LL = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double, C.c_longlong
 _GP = C.POINTER(Geom)
 
 # name -> (restype, argtypes).  Must list every symbol include/effq_hip.h declares.
@@ -68,6 +68,9 @@ SIGNATURES = {
     "effq_fp_check": (_I, [_P, _P, _P]),
     "effq_gram_ws_bytes": (_SZ, [_GP, _I]),
     "effq_gram_accum": (_I, [_P, _P, _P, _GP, _I, _P, _P, _I, _P, _SZ, _P]),
+    "effq_gram_i8_supported": (_I, [_GP, _I]),
+    "effq_gram_i8_ws_bytes": (_SZ, [_GP, _I]),
+    "effq_gram_accum_i8": (_I, [_P, _P, _GP, _I, _P, _I, _P, _P, _P, _I, _LL, _P, _P, _I, _P, _SZ, _P]),
     "effq_ainv_ld": (_I, [_I]),
     "effq_spd_inverse_ws_bytes": (_SZ, [_I]),
     "effq_spd_inverse": (_I, [_P, _I, _I, _D, _D, _P, _P, _SZ, _P]),

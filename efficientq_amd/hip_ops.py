@@ -69,6 +69,7 @@ class HipOps:
         self.device = device
         self._red_ws = torch.zeros(self.lib.effq_reduce_ws_bytes(), dtype=torch.uint8, device=device)
         self._ws = {}
+        self._att_cache = {}
 
     # -- plumbing ---------------------------------------------------------------------------
     @property
@@ -222,6 +223,74 @@ class HipOps:
         ws = self._workspace("gram", need)
         check(self.lib.effq_gram_accum(_ptr(x), _ptr(a), _ptr(y), C.byref(geom), int(has_bias), _ptr(A0), _ptr(B0),
                                        acc, _ptr(ws), ws.numel(), self.stream), "effq_gram_accum")
+        return A0, B0
+
+    def gram_i8_supported(self, geom: Geom, act_levels: int) -> bool:
+        return bool(self.lib.effq_gram_i8_supported(C.byref(geom), int(act_levels)))
+
+    GRAM_I8_MAX_CLASSES = 16
+
+    def att_classes(self, att: Optional[torch.Tensor]):
+        """Voxel list sorted by attention weight for effq_gram_accum_i8: (vox_list int32 padded per class to
+        multiples of 128 with -1, chunk_cls int32, cls_w float32, ncls).  None when the mask has more distinct
+        values than the kernel takes (the caller then uses the fp32 Gram).  Plumbing only (a stable sort of
+        the voxel indices); cached per mask tensor, the pyramid level is shared by several layers."""
+        if att is None:
+            return (None, None, None, 1)
+        key = (att.data_ptr(), att.numel(), att._version)
+        hit = self._att_cache.get(key)
+        if hit is not None:
+            return hit[1]
+        flat = self._f32(att).reshape(-1)
+        vals, inv = torch.unique(flat, return_inverse=True)
+        k = int(vals.numel())
+        if k > self.GRAM_I8_MAX_CLASSES:
+            res = None
+        else:
+            counts = torch.bincount(inv, minlength=k)
+            padded = (counts + 127) // 128 * 128
+            order = torch.argsort(inv, stable=True)
+            starts = torch.cumsum(counts, 0) - counts
+            pstarts = torch.cumsum(padded, 0) - padded
+            cls_sorted = inv[order]
+            dest = pstarts[cls_sorted] + (torch.arange(flat.numel(), device=flat.device) - starts[cls_sorted])
+            lst = torch.full((int(padded.sum().item()),), -1, dtype=torch.int32, device=flat.device)
+            lst[dest] = order.to(torch.int32)
+            chunk_cls = torch.repeat_interleave(torch.arange(k, dtype=torch.int32, device=flat.device), padded // 128)
+            res = (lst, chunk_cls.contiguous(), vals.to(torch.float32).contiguous(), k)
+        if len(self._att_cache) > 16:
+            self._att_cache.clear()
+        self._att_cache[key] = (att, res)     # holding the mask keeps its address from being reused
+        return res
+
+    def gram_i8(self, xidx_ndhwc: torch.Tensor, att_cls, y_ndhwc: torch.Tensor, geom: Geom, has_bias: bool,
+                act_alpha: torch.Tensor, act_levels: int, A0: Optional[torch.Tensor] = None,
+                B0: Optional[torch.Tensor] = None):
+        """A0/B0 of gram() for an already quantised input, exact on the i8 matrix cores (effq_gram_accum_i8).
+        att_cls = att_classes(att)."""
+        if xidx_ndhwc.dtype != torch.uint8 or not xidx_ndhwc.is_contiguous():
+            raise _lib.EffqError("gram_i8 wants contiguous uint8 level ids")
+        y = self._f32(y_ndhwc)
+        _check_shapes(geom, xidx_ndhwc, y=y)
+        lst, chunk_cls, cls_w, ncls = att_cls
+        if lst is not None:
+            od, oh, ow = geom.out_dims()
+            if (int(lst.numel()) < geom.N * od * oh * ow or lst.numel() % 128 or
+                    chunk_cls.numel() * 128 != lst.numel() or cls_w.numel() != ncls):
+                raise _lib.EffqError("gram_i8: voxel list does not match the output volume")
+        n = geom.C1 * geom.KD * geom.KH * geom.KW + int(has_bias)
+        acc = int(A0 is not None)
+        if A0 is not None and (tuple(A0.shape) != (n, n) or tuple(B0.shape) != (geom.C2, n)):
+            raise _lib.EffqError("gram_i8: A0/B0 shapes do not match the geometry")
+        if A0 is None:
+            A0 = torch.empty(n, n, dtype=torch.float32, device=self.device)
+            B0 = torch.empty(geom.C2, n, dtype=torch.float32, device=self.device)
+        al = self._f32(act_alpha.reshape(1))
+        ws = self._workspace("gram_i8", self.lib.effq_gram_i8_ws_bytes(C.byref(geom), int(ncls)))
+        check(self.lib.effq_gram_accum_i8(_ptr(xidx_ndhwc), _ptr(y), C.byref(geom), int(has_bias), _ptr(al),
+                                          int(act_levels), _ptr(lst), _ptr(chunk_cls), _ptr(cls_w), int(ncls),
+                                          0 if lst is None else int(lst.numel()), _ptr(A0), _ptr(B0), acc, _ptr(ws),
+                                          ws.numel(), self.stream), "effq_gram_accum_i8")
         return A0, B0
 
     # -- a7 -----------------------------------------------------------------------------------

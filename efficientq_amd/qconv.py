@@ -233,6 +233,11 @@ class EfficientQConvHIP(PTQConv):
         # exact-integer evaluation of the 200 per-iteration losses (north_star's "int-simulated" forward)
         use_i8 = bool(self.q_act and not self._act_inited and self.lwq_exact_int and
                       getattr(ops, "conv_i8_supported", lambda *a: False)(geom, self.qlvl_act, self.qlvl_w))
+        # ... and of the Gram system (exact integer sums, weights applied per attention class)
+        use_gi8 = bool(self.q_act and not self._act_inited and self.lwq_exact_int and
+                       getattr(ops, "gram_i8_supported", lambda *a: False)(geom, self.qlvl_act))
+        att_cls = ops.att_classes(att) if use_gi8 else None
+        use_gi8 = att_cls is not None
         if self.q_act:                                                     # (:64-72)
             if self._act_inited:
                 xq = to_ndhwc(self._quantize_act(x))
@@ -240,7 +245,7 @@ class EfficientQConvHIP(PTQConv):
                 a_act, act_iters, st = ops.fit_scale(xn, self.qlvl_act, 0.0, 1.0, reducer=red or None,
                                                      guess_iters=12 * self.qlvl_act)
                 self.alpha_act.data = torch.tensor(a_act, dtype=x.dtype, device=dev)
-                xq, _, xidx = ops.quant_dequant_f64path(xn, st, self.qlvl_act, 0.0, 1.0, want_idx=use_i8)
+                xq, _, xidx = ops.quant_dequant_f64path(xn, st, self.qlvl_act, 0.0, 1.0, want_idx=use_i8 or use_gi8)
         else:
             xq = xn
 
@@ -248,7 +253,10 @@ class EfficientQConvHIP(PTQConv):
         rho_m = self.lwq_rho_max * rho_scale
         eta = self.lwq_eta * rho_scale
 
-        A0, B0 = ops.gram(xq, att, yn, geom, has_b)                        # (:87-91, solver.py:282-314)
+        if use_gi8:                                                        # (:87-91, solver.py:282-314)
+            A0, B0 = ops.gram_i8(xidx, att_cls, yn, geom, has_b, self.alpha_act.data, self.qlvl_act)
+        else:
+            A0, B0 = ops.gram(xq, att, yn, geom, has_b)
         red(A0)
         red(B0)
 
@@ -339,7 +347,7 @@ class EfficientQConvHIP(PTQConv):
         self.last_trace = dict(rho_scale=rho_scale, best_iter=int(best_h[1]), best_mse=best_h[0] / numel,
                                final_mse=fin_h[0] / numel, layer_loss=lossf, act_iters=act_iters,
                                w_iters=w_iters, alpha_w=a_w, loss_history=[h / numel for h in hist],
-                               exact_int=use_i8)
+                               exact_int=use_i8, exact_gram=use_gi8)
 
     def compute_quant_error(self, output_fp, Qw, Qact):
         """EfficientQConv.py:168-172."""

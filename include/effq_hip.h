@@ -128,6 +128,22 @@ int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc
                     int has_bias, float* A0, float* B0, int accumulate, void* ws, size_t ws_bytes,
                     void* stream);
 
+/* The same A0/B0 for a layer whose input is already quantised (EfficientQConv.py:64-72 ran first), evaluated
+ * exactly on the i8 matrix cores: xidx = level ids of the quantised input (uint8, NDHWC, value k means
+ * xhat = alpha_act*k/(act_levels-1)), act_alpha_dev = device float.  The attention weights enter as a voxel
+ * list sorted by weight value: vox_list[n_list] (output-voxel indices, -1 = padding; every run of 128 entries
+ * has one weight), chunk_cls[n_list/128] = class of each run, cls_w_dev[ncls] = the class weights (device
+ * floats, ncls <= 16).  vox_list == NULL: all weights 1 (then chunk_cls = NULL, ncls = 1, n_list = 0).
+ * Requires effq_gram_i8_supported (C1 % 16 == 0, at most 31 taps, act_levels <= 128); results equal
+ * effq_gram_accum on xhat up to the fp32 rounding of that path (integer sums here are exact).
+ * ws: effq_gram_i8_ws_bytes(geom, ncls). */
+int effq_gram_i8_supported(const effq_geom* g, int act_levels);
+size_t effq_gram_i8_ws_bytes(const effq_geom* g, int ncls);
+int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const effq_geom* g, int has_bias,
+                       const float* act_alpha_dev, int act_levels, const int32_t* vox_list,
+                       const int32_t* chunk_cls, const float* cls_w_dev, int ncls, long long n_list,
+                       float* A0, float* B0, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- a7: getAB + solve (solver.py:316-345) --------------------------------------
  * Ainv = (A0 + rho*I' + eta*I)^-1 in fp64 (I' has 0 on the bias diagonal), stored fp32 as n rows of
  * effq_ainv_ld(n) floats (row padding is zero; exactly symmetric).

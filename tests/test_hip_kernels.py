@@ -164,6 +164,74 @@ def test_gram_vs_oracle(ops, c1, c2, k, s, p, S):
     assert (B1 - B0).abs().max() <= 3e-6 * ps.B0.abs().max()
 
 
+@pytest.mark.parametrize("c1,c2,k,s,p,S,La,att_kind,bias", [
+    (32, 32, 3, 1, 1, 8, 4, "int", True),        # the BraTS 32-channel layer shape in small
+    (16, 24, 3, 1, 1, 7, 16, "float", True),     # c2 padded to 32, non-integer class weights, odd sizes
+    (32, 16, 3, 2, 1, 9, 4, "none", True),       # stride 2, no attention
+    (48, 3, 1, 1, 0, 6, 128, "int", False),      # 1x1, no bias, the widest level range
+    (64, 32, 3, 1, 1, 6, 4, "many", True),       # 16 distinct weights
+])
+def test_gram_i8_exact_vs_f32_and_oracle(ops, c1, c2, k, s, p, S, La, att_kind, bias):
+    """effq_gram_accum_i8 (integer Gram on the i8 matrix cores, weights applied per sorted class) against the
+    fp64 value of the same sums, the fp32 kernel and the oracle's getA0B0 on xhat = alpha*k/(La-1)."""
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(c1 * 131 + c2 + La)
+    N = 2
+    shape = (N, c1, S, S + 1, S + 2)
+    idx = torch.randint(0, La, shape, generator=gen).to(torch.uint8)
+    alpha = torch.tensor(0.7312, dtype=torch.float32)
+    xhat = (alpha.double() * idx.double() / (La - 1)).float()
+    w = torch.randn(c2, c1, k, k, k, generator=gen) * 0.1
+    b = torch.randn(c2, generator=gen) if bias else None
+    y = F.conv3d(torch.relu(torch.randn(shape, generator=gen)), w, b, s, p) * 3.7
+    vshape = y[:, 0].shape
+    if att_kind == "int":
+        att = torch.randint(1, 5, vshape, generator=gen).float()
+    elif att_kind == "float":
+        att = torch.tensor([1.0, 2.5, 17.25])[torch.randint(0, 3, vshape, generator=gen)]
+    elif att_kind == "many":
+        att = torch.randint(1, 17, vshape, generator=gen).float()
+    else:
+        att = None
+    geom = make_geom(shape, c2, k, s, p)
+    assert ops.gram_i8_supported(geom, La)
+    cls = ops.att_classes(dev(att) if att is not None else None)
+    assert cls is not None
+    A0, B0 = ops.gram_i8(dev(_ndhwc(idx)), cls, dev(_ndhwc(y)), geom, bias, dev(alpha), La)
+    # fp64 reference of the same sums
+    X = torch.from_numpy(O.patch_matrix(idx.float().numpy(), (k, k, k), s, p).copy()).double()
+    X = X * (alpha.double() / (La - 1))
+    if bias:
+        X = torch.cat([X, torch.ones(1, X.shape[1], dtype=torch.float64)])
+    a = att.reshape(1, -1).double() if att is not None else torch.ones(1, X.shape[1], dtype=torch.float64)
+    ymat = y.permute(1, 0, 2, 3, 4).reshape(c2, -1).double()
+    wantA, wantB = 2 * (X * a) @ X.T, 2 * (ymat * a) @ X.T
+    assert (A0.cpu().double() - wantA).abs().max() <= 2e-7 * wantA.abs().max()      # fp32 output rounding only
+    assert (B0.cpu().double() - wantB).abs().max() <= 2e-7 * wantB.abs().max()
+    assert torch.equal(A0, A0.T)
+    # the fp32 kernel on xhat agrees to its own rounding
+    Af, Bf = ops.gram(dev(_ndhwc(xhat)), dev(att) if att is not None else None, dev(_ndhwc(y)), geom, bias)
+    assert (A0 - Af).abs().max() <= 3e-6 * wantA.abs().max()
+    assert (B0 - Bf).abs().max() <= 3e-6 * wantB.abs().max()
+    # sharded accumulation == unsharded
+    g1 = make_geom((1,) + shape[1:], c2, k, s, p)
+    c0 = ops.att_classes(dev(att[:1].contiguous())) if att is not None else cls
+    c1_ = ops.att_classes(dev(att[1:].contiguous())) if att is not None else cls
+    A1, B1 = ops.gram_i8(dev(_ndhwc(idx[:1])), c0, dev(_ndhwc(y[:1])), g1, bias, dev(alpha), La)
+    A1, B1 = ops.gram_i8(dev(_ndhwc(idx[1:])), c1_, dev(_ndhwc(y[1:])), g1, bias, dev(alpha), La, A1, B1)
+    assert (A1 - A0).abs().max() <= 3e-7 * wantA.abs().max()
+    assert (B1 - B0).abs().max() <= 3e-7 * wantB.abs().max()
+
+
+def test_gram_i8_rejects_what_it_cannot_do(ops):
+    from efficientq_amd.hip_ops import make_geom
+    assert not ops.gram_i8_supported(make_geom((1, 4, 8, 8, 8), 32, 3, 2, 1), 4)       # C1 % 16
+    assert not ops.gram_i8_supported(make_geom((1, 32, 8, 8, 8), 32, 3, 1, 1), 256)    # levels beyond int8
+    assert not ops.gram_i8_supported(make_geom((1, 16, 8, 8, 8), 8, 5, 1, 2), 4)       # 125 taps
+    att = torch.arange(17 * 8, dtype=torch.float32, device="cuda:0").reshape(1, 17, 8, 1)
+    assert ops.att_classes(att) is None                                              # too many distinct weights
+
+
 @pytest.mark.parametrize("n,c2", [(28, 8), (217, 16), (865, 32), (130, 64)])
 def test_spd_inverse_and_prox(ops, n, c2):
     gen = torch.Generator().manual_seed(n)

@@ -125,8 +125,9 @@ def test_whole_calibration_matches_reference(gold, task, fname):
 
 
 def test_exact_int_and_fp32_loss_paths_agree_on_a_layer():
-    """Same layer calibrated with the per-iteration losses on the i8 matrix cores (exact) and on the f32
-    matrix cores: the early iteration losses agree to fp32 rounding, the result to the plateau tolerance."""
+    """Same layer calibrated with the Gram system and the per-iteration losses on the i8 matrix cores (exact
+    integer sums) and on the f32 matrix cores: the first iteration losses agree to fp32 rounding (until the
+    first weight index flips on a rounding tie, iteration 5 here), the result to the plateau tolerance."""
     from efficientq_amd.qconv import EfficientQConvHIP
     res = {}
     for exact in (True, False):
@@ -145,10 +146,10 @@ def test_exact_int_and_fp32_loss_paths_agree_on_a_layer():
         conv.set_quantizing()
         with torch.no_grad():
             conv(x.to(DEV))
-        assert conv.last_trace["exact_int"] == exact
+        assert conv.last_trace["exact_int"] == exact and conv.last_trace["exact_gram"] == exact
         res[exact] = (np.array(conv.last_trace["loss_history"]), float(conv.layer_loss[0].split(":")[1]))
     hi, hf = res[True][0], res[False][0]
-    assert np.all(np.abs(hi[:5] - hf[:5]) <= 2e-6 * hf[:5]), (hi[:5], hf[:5])
+    assert np.all(np.abs(hi[:4] - hf[:4]) <= 5e-6 * hf[:4]), (hi[:5], hf[:5])
     assert abs(res[True][1] - res[False][1]) <= 5e-3 * res[False][1]
 
 
