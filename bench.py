@@ -48,6 +48,7 @@ def build_model(levels, device):
     return args, model
 
 
+PEAK_I8_MFMA_TOPS = 5033.2         # MI355X dense int8 matrix peak (MI355X_MICROARCH.md: = fp8 dense)
 PEAK_F64_MFMA_TFLOPS = 78.6       # MI355X fp64 matrix peak (vendor)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
@@ -86,6 +87,7 @@ class OpTimer:
             self._wrap(ops, "conv_step", lambda x, w, b, geom, y=None, att=None, **kw: gkey(geom)),
             self._wrap(ops, "conv_step_i8", lambda xi, gq, b, geom, *a, **kw: gkey(geom)),
             self._wrap(ops, "gram", lambda x, att, y, geom, hb, *a, **kw: gkey(geom)),
+            self._wrap(ops, "gram_i8", lambda xi, cls, y, geom, *a, **kw: gkey(geom)),
             self._wrap(ops, "spd_inverse", lambda A0, *a, **kw: (int(A0.shape[0]),)),
             self._wrap(ops, "prox_solve", lambda B0, *a, **kw: (int(B0.shape[0]), int(B0.shape[1]))),
         ]
@@ -94,7 +96,7 @@ class OpTimer:
     @staticmethod
     def _work(key):
         op = key[0].replace("@side", "")
-        if op in ("conv_step", "conv_step_i8", "gram"):
+        if op in ("conv_step", "conv_step_i8", "gram", "gram_i8"):
             N, c1, c2, D, H, W, k, s = key[1:]
             od, oh, ow = (D + 2 * (k // 2) - k) // s + 1, (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
             V, Vin = N * od * oh * ow, N * D * H * W
@@ -106,6 +108,10 @@ class OpTimer:
                         f"k_conv3d_i8 ({c1}->{c2}, 3^3, {N}x{od}x{oh}x{ow} voxels: 4*c2 B of target + c1 B of level "
                         f"ids per voxel, i8 MFMA exact)")
             n = c1 * k ** 3 + 1
+            if op == "gram_i8":
+                # integer ops of the products that are needed: x-x upper triangle + 4 y digit rows per channel
+                return ("mfma", 1.0 * n * n * V + 2.0 * 4 * c2 * n * V, "i8 MFMA", PEAK_I8_MFMA_TOPS, "TOP/s",
+                        f"k_gram_i8 (n={n}, {V} voxels; n^2 V (upper triangle) + 8 c2 n V int8 op, exact)")
             return ("mfma", 2.0 * n * n * V + 2.0 * c2 * n * V, "f32 MFMA", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                     f"k_gram (n={n}, {V} voxels; 2n^2V+2c2nV flop, upper triangle computed)")
         if op == "spd_inverse":
@@ -124,7 +130,7 @@ class OpTimer:
             ms = [a.elapsed_time(b) for a, b in pairs]
             bound, work, pname, peak, unit, label = self._work(key)
             avg = sum(ms) / len(ms)
-            ach = work / (avg * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+            ach = work / (avg * 1e-3) / (1e12 if unit in ("TFLOP/s", "TOP/s") else 1e9)
             side = key[0].endswith("@side")
             tkey = key[0].replace("@side", "") + "|" + ",".join(str(v) for v in key[1:])
             tr = traffic.get(tkey)
@@ -139,6 +145,9 @@ class OpTimer:
         rows.sort(key=lambda r: (r["overlapped"], -r["total_ms"]))
         if not rows:
             return None, []
+        for r in rows:
+            log(f"[ops] {r['total_ms']:9.1f} ms {r['launches']:6d} x {r['avg_ms']:9.4f} ms  {r['frac']:.3f} of {r['bound']} "
+                f"peak  {r['kernel'][:90]}")
         return rows[0], rows[1:7]
 
 

@@ -43,6 +43,7 @@ struct GramI8Params {
   long long V;
   int nchunks, nsplit, cps, ncls;
   long long* slabs;   // [ncls][npairs][128*128]
+  int debug;          // profiling ablations (EFFQ_GI8_DEBUG): 1 no MFMA, 2 no global loads, 3 no LDS staging
 };
 
 __device__ __forceinline__ void gi_transpose4(int r0, int r1, int r2, int r3, int (&o)[4]) {
@@ -79,7 +80,9 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
   const int c_end = min(c_begin + p.cps, p.nchunks);
   if (c_begin >= c_end) return;   // uniform over the workgroup
 
-  // staging role: 16 rows (16*rg ..) x 4 voxels (4*vg ..) of each panel
+  // staging role: 16 rows (16*rg ..) x 4 voxels of each panel.  The 4 voxels are list slots vg, vg+32, vg+64,
+  // vg+96 of the chunk, so that one load instruction walks 32 CONSECUTIVE voxels (whole cache lines); they
+  // land in K positions 4*vg+q of the LDS row - the K order is arbitrary as long as both panels share it.
   const int vg = tid & 31, rg = tid >> 5;
   // row-group descriptor: kind 0 x cell, 1 y digit cell, 2 ones cell, 3 padding
   int kindI, tapI, offI, kindJ, tapJ, offJ;
@@ -153,14 +156,14 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
   {                                                                                              \
     okb = 0;                                                                                     \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                              \
-      const gi_v4i e = tbl[(slot) * GI_KC + 4 * vg + q];                                         \
+      const gi_v4i e = tbl[(slot) * GI_KC + vg + 32 * q];                                        \
       const unsigned m = (unsigned)e[1];                                                         \
       const unsigned okx = (m >> (tap)) & 1u, okv = m >> 31;                                     \
       const unsigned ok = (kind == 0) ? okx : ((kind <= 2) ? okv : 0u);                          \
       const int ax = okx ? (e[0] * p.C1 + (off)) : 0;                                            \
       const int ay = e[2] * ystride + (off);                                                     \
       const int addr = (kind == 0) ? ax : ((kind == 1) ? ay : 0);                                \
-      val[q] = *reinterpret_cast<const gi_v4i*>(src + addr);                                     \
+      val[q] = *reinterpret_cast<const gi_v4i*>(src + ((p.debug == 2) ? 0 : addr));             \
       okb |= ok << q;                                                                            \
     }                                                                                            \
   }
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
     GI_FETCH(vI, okI, kindI, tapI, offI, srcI, b ^ 1)          // chunk c+1 (its table was built last iteration)
     if (!diag) GI_FETCH(vJ, okJ, kindJ, tapJ, offJ, srcJ, b ^ 1)
     __builtin_amdgcn_sched_barrier(0);
-    if (live) {
+    if (live && p.debug != 1) {
       const unsigned char* PI = panI + b * GI_PANEL + (wr * 64 + li) * GI_RS + lh * 16;
       const unsigned char* PJ = (diag ? panI : panJ) + b * GI_PANEL + (wc * 64 + li) * GI_RS + lh * 16;
 #pragma unroll
@@ -252,8 +255,10 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
     }
     if (cls_next != cls_cur && live) flush(cls_cur);
     if (tid < GI_KC) tbl[b * GI_KC + tid] = build_entry(list_value(lraw, c2, tid));   // chunk c+2 replaces chunk c
-    stage(panI + (b ^ 1) * GI_PANEL, vI, okI, kindI);
-    if (!diag) stage(panJ + (b ^ 1) * GI_PANEL, vJ, okJ, kindJ);
+    if (p.debug != 3) {
+      stage(panI + (b ^ 1) * GI_PANEL, vI, okI, kindI);
+      if (!diag) stage(panJ + (b ^ 1) * GI_PANEL, vJ, okJ, kindJ);
+    }
     cls_cur = cls_next;
     cls_next = (c + 2 < c_end) ? (has_cls ? cls_raw : 0) : -1;
     __syncthreads();
@@ -394,7 +399,8 @@ static int gram_i8_plan(const effq_geom* g, int ncls, long long n_list, GramI8Pa
   p.nchunks = (int)nchunks;
   p.ncls = ncls;
   // splits: ~1536 workgroups, at least 4 chunks each, at most GI_MAX_CPS (int32 accumulator range)
-  long long want = (1536 + p.npairs - 1) / p.npairs;
+  static const int wgs = getenv("EFFQ_GI8_WGS") ? atoi(getenv("EFFQ_GI8_WGS")) : 3072;   // tuning aid
+  long long want = (wgs + p.npairs - 1) / p.npairs;
   if (want > nchunks / 4) want = nchunks / 4;
   if (want < 1) want = 1;
   long long cps = (nchunks + want - 1) / want;
@@ -458,6 +464,10 @@ int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const ef
   p.yd = yd;
   p.vox_list = vox_list;
   p.chunk_cls = chunk_cls;
+  {
+    const char* dbg = getenv("EFFQ_GI8_DEBUG");
+    p.debug = dbg ? atoi(dbg) : 0;
+  }
   hipStream_t st = as_stream(stream);
   EFFQ_HIP(hipMemsetAsync(base, 0, 256 + slab_bytes, st));
   const size_t ny = (size_t)p.V * p.C2;
