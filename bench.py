@@ -74,7 +74,8 @@ class OpTimer:
             r = inner(*a, **kw)
             e1.record()
             # work issued on the side stream overlaps the calibration stream: timed, but kept out of the ranking
-            side = torch.cuda.current_stream() != torch.cuda.default_stream()
+            # (the loss stream carries the critical-path loss convs and counts as calibration work)
+            side = getattr(ops, "_side", None) is not None and torch.cuda.current_stream() == ops._side
             rec.setdefault((name + ("@side" if side else ""),) + key, []).append((e0, e1))
             return r
         setattr(ops, name, call)

@@ -76,6 +76,12 @@ class HipOps:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def loss_stream(self):
+        """The stream the per-iteration loss evaluation runs on, one iteration behind the ADMM chain."""
+        if getattr(self, "_loss", None) is None:
+            self._loss = torch.cuda.Stream(self.device)
+        return self._loss
+
     def side_stream(self):
         """A second HIP stream of this device for work that is independent of the calibration stream."""
         if getattr(self, "_side", None) is None:

@@ -25,6 +25,8 @@ from .hip_ops import from_ndhwc, make_geom, to_ndhwc
 LWQ_ITER, LWQ_RHO, LWQ_RHO_MAX, LWQ_ETA, RHO_PERIOD = 200, 10.0, 1000.0, 1.0, 50
 import os as _os
 EXACT_INT_DEFAULT = _os.environ.get("EFFQ_EXACT_INT", "1") != "0"
+# evaluate the loss of iteration i on a second stream while the chain computes iteration i+1
+OVERLAP_LOSS_DEFAULT = _os.environ.get("EFFQ_OVERLAP_LOSS", "1") != "0"
 
 
 def get_ops(device):
@@ -190,6 +192,7 @@ class EfficientQConvHIP(PTQConv):
         self.lwq_trace = kwQ.get('lwq_trace', False)   # record the per-iteration loss (one host sync each)
         # evaluate the per-iteration losses on the i8 matrix cores (exact int32 accumulation) where supported
         self.lwq_exact_int = kwQ.get('lwq_exact_int', EXACT_INT_DEFAULT)
+        self.lwq_overlap_loss = kwQ.get('lwq_overlap_loss', OVERLAP_LOSS_DEFAULT)
 
     @staticmethod
     def _std(m: torch.Tensor) -> float:
@@ -261,18 +264,25 @@ class EfficientQConvHIP(PTQConv):
         red(B0)
 
         f32 = dict(dtype=torch.float32, device=dev)
-        G = W0.clone()
+        # The loss of iteration i (conv + MSE + keep-best) only feeds the best-iterate selection; the chain
+        # prox -> scale fixed point -> projection/dual of iteration i+1 does not wait for it.  Everything the
+        # loss reads is kept per iteration parity (G, its int8 numerators, the bias, the scale state), so the
+        # loss stream evaluates iteration i while the calibration stream computes i+1.
+        Gb = [torch.empty_like(W0), W0.clone()]              # G(i) lives in Gb[i & 1]; G(-1) = W0
         dual = torch.zeros_like(W0)
         wstar = torch.empty_like(W0)
         v = torch.empty_like(W0)
-        bstar = torch.empty(c2, **f32) if has_b else None
+        bsb = [torch.empty(c2, **f32), torch.empty(c2, **f32)] if has_b else [None, None]
         best_G = torch.empty_like(W0)
         best_b = torch.empty(c2, **f32) if has_b else None
         sqerr = torch.zeros(2, dtype=torch.float64, device=dev)
         best = torch.zeros(2, dtype=torch.float64, device=dev)
-        st_w = ops.new_fp_state()
-        Gq = torch.empty(W0.shape, dtype=torch.int8, device=dev) if use_i8 else None
+        stb = [ops.new_fp_state(), ops.new_fp_state()]
+        Gqb = [torch.empty(W0.shape, dtype=torch.int8, device=dev) for _ in range(2)] if use_i8 else [None, None]
         fp_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        loss_s = getattr(ops, "loss_stream", lambda: None)() if self.lwq_overlap_loss else None
+        main_s = torch.cuda.current_stream(dev) if loss_s is not None else None
+        ev_loss = [None, None]
         # A = A0 + rho*I' + eta*I changes only with rho, and the rho schedule is known up front (5 values per
         # layer): the first inverse is formed on the calibration stream, the later ones on a side stream under
         # the ADMM iterations that precede their first use (EfficientQConv.py:129-137 fixes when that is).
@@ -293,6 +303,8 @@ class EfficientQConvHIP(PTQConv):
                     ev.record(side)
                     inv_of[r_] = (buf, ev)
         Ainv, rho_of_inv = None, None
+        import time as _time
+        t_loop0 = _time.perf_counter()
         guess = 16
         a_w = 1.0
         w_iters, hist = [], []
@@ -304,7 +316,11 @@ class EfficientQConvHIP(PTQConv):
                 if ev is not None:
                     torch.cuda.current_stream(dev).wait_event(ev)
                 rho_of_inv = rho
-            ops.prox_solve(B0, Ainv, W0, b0, G, dual, rho, eta, wstar, bstar)
+            p_ = i & 1
+            if ev_loss[p_] is not None:             # the loss of iteration i-2 is done with this parity's buffers
+                main_s.wait_event(ev_loss[p_])
+            G, Gq, bstar, st_w = Gb[p_], Gqb[p_], bsb[p_], stb[p_]
+            ops.prox_solve(B0, Ainv, W0, b0, Gb[p_ ^ 1], dual, rho, eta, wstar, bstar)
             it_w = ops.weight_fixed_point(wstar, dual, v, self.qlvl_w, st_w, guess)   # (:108) no host sync
             ops.fp_check(st_w, fp_err)                                                # when the tensor is small
             if it_w is not None:
@@ -315,21 +331,40 @@ class EfficientQConvHIP(PTQConv):
                 dual_div = 2.0 if rho * 2 <= rho_m else rho_m / rho
             if use_i8:
                 ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div, Gq)
-                ops.conv_step_i8(xidx, Gq, bstar, geom, yn, self.alpha_act.data, self.qlvl_act, st_w, self.qlvl_w,
-                                 sqerr)
             else:
                 ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div)
-                ops.conv_step(xq, G, bstar, geom, yn, None, sqerr=sqerr)   # unweighted MSE (quirk Q5)
-            red(sqerr)
-            if self.lwq_trace:
-                hist.append(sqerr[0].item())
-            ops.admm_keep_best(sqerr, best, i, G, bstar, best_G, best_b)
+
+            def loss_step(i=i, G=G, Gq=Gq, bstar=bstar, st_w=st_w):
+                if use_i8:
+                    ops.conv_step_i8(xidx, Gq, bstar, geom, yn, self.alpha_act.data, self.qlvl_act, st_w,
+                                     self.qlvl_w, sqerr)
+                else:
+                    ops.conv_step(xq, G, bstar, geom, yn, None, sqerr=sqerr)   # unweighted MSE (quirk Q5)
+                red(sqerr)
+                if self.lwq_trace:
+                    hist.append(sqerr[0].item())
+                ops.admm_keep_best(sqerr, best, i, G, bstar, best_G, best_b)
+
+            if loss_s is None:
+                loss_step()
+            else:
+                ev = torch.cuda.Event()
+                ev.record(main_s)
+                with torch.cuda.stream(loss_s):
+                    loss_s.wait_event(ev)
+                    loss_step()
+                    ev_loss[p_] = torch.cuda.Event()
+                    ev_loss[p_].record(loss_s)
             if i % RHO_PERIOD == 0:
                 rho = rho * 2 if rho * 2 <= rho_m else rho_m
 
+        t_enq = _time.perf_counter() - t_loop0     # host time to enqueue the 200 iterations (diagnostic)
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
-        a_w, _, _ = ops.read_fp_state(st_w)                                # one sync per layer
+        if loss_s is not None:
+            torch.cuda.current_stream(dev).wait_stream(loss_s)
+        a_w, _, _ = ops.read_fp_state(stb[(self.lwq_iter - 1) & 1])        # one sync per layer
+        t_loop = _time.perf_counter() - t_loop0
         if fp_err.item() != 0:                                             # layer_helper.py:62-64
             raise RuntimeWarning(f'Exceed maximum iteration ({100 * self.qlvl_w}) for alpha optimization')
         self.weight.data = best_G.reshape(self.weight.shape)               # (:147-158)
@@ -347,7 +382,7 @@ class EfficientQConvHIP(PTQConv):
         self.last_trace = dict(rho_scale=rho_scale, best_iter=int(best_h[1]), best_mse=best_h[0] / numel,
                                final_mse=fin_h[0] / numel, layer_loss=lossf, act_iters=act_iters,
                                w_iters=w_iters, alpha_w=a_w, loss_history=[h / numel for h in hist],
-                               exact_int=use_i8, exact_gram=use_gi8)
+                               exact_int=use_i8, exact_gram=use_gi8, host_enqueue_s=t_enq, admm_loop_s=t_loop)
 
     def compute_quant_error(self, output_fp, Qw, Qact):
         """EfficientQConv.py:168-172."""

@@ -22,7 +22,8 @@ for name, q in model.named_modules():
         orig = q.ptq
         def timed(x, _o=orig, _n=name):
             torch.cuda.synchronize(); t0 = time.time(); _o(x); torch.cuda.synchronize(); times[_n] = time.time() - t0
-            print(f"  {_n:45s} {times[_n]:7.3f}s  in={tuple(x.shape)}", flush=True)
+            tr = _o.__self__.last_trace
+            print(f"  {_n:45s} {times[_n]:7.3f}s  loop {tr['admm_loop_s']:6.3f}s host-enqueue {tr['host_enqueue_s']:6.3f}s  in={tuple(x.shape)}", flush=True)
         q.ptq = timed
 res = K.calibrate_model(model, vols, "brats", args.init_stride)
 print(f"FP pass {res['t1']-res['t0']:.3f}s  PTQ pass {res['t2']-res['t1']:.3f}s  total {res['t2']-res['t0']:.3f}s  vols/s {N/(res['t2']-res['t0']):.4f}")
