@@ -87,6 +87,7 @@ class OpTimer:
         undo = [
             self._wrap(ops, "conv_step", lambda x, w, b, geom, y=None, att=None, **kw: gkey(geom)),
             self._wrap(ops, "conv_step_i8", lambda xi, gq, b, geom, *a, **kw: gkey(geom)),
+            self._wrap(ops, "conv_step_i8s", lambda xi, gq, b, geom, *a, **kw: gkey(geom)),
             self._wrap(ops, "gram", lambda x, att, y, geom, hb, *a, **kw: gkey(geom)),
             self._wrap(ops, "gram_i8", lambda xi, cls, y, geom, *a, **kw: gkey(geom)),
             self._wrap(ops, "spd_inverse", lambda A0, *a, **kw: (int(A0.shape[0]),)),
@@ -97,13 +98,17 @@ class OpTimer:
     @staticmethod
     def _work(key):
         op = key[0].replace("@side", "")
-        if op in ("conv_step", "conv_step_i8", "gram", "gram_i8"):
+        if op in ("conv_step", "conv_step_i8", "conv_step_i8s", "gram", "gram_i8"):
             N, c1, c2, D, H, W, k, s = key[1:]
             od, oh, ow = (D + 2 * (k // 2) - k) // s + 1, (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
             V, Vin = N * od * oh * ow, N * D * H * W
             if op == "conv_step":
                 return ("mfma", 2.0 * c2 * c1 * k ** 3 * V, "f32 MFMA", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                         f"k_conv3d* ({c1}->{c2}, {k}^3/s{s}, {N}x{od}x{oh}x{ow} voxels, f32 MFMA)")
+            if op == "conv_step_i8s":
+                return ("hbm", 4.0 * c2 * V + 1.0 * c1 * Vin, "HBM", PEAK_HBM_GBS, "GB/s",
+                        f"k_conv3d_i8s ({c1}->{c2}, {k}^3/s{s}, {N}x{od}x{oh}x{ow} voxels: 4*c2 B of target + c1 B of "
+                        f"level ids per input voxel, i8 MFMA exact)")
             if op == "conv_step_i8":
                 return ("hbm", 4.0 * c2 * V + 1.0 * c1 * Vin, "HBM", PEAK_HBM_GBS, "GB/s",
                         f"k_conv3d_i8 ({c1}->{c2}, 3^3, {N}x{od}x{oh}x{ow} voxels: 4*c2 B of target + c1 B of level "

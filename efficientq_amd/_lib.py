@@ -79,6 +79,9 @@ SIGNATURES = {
     "effq_admm_presum": (_I, [_P, _P, _P, _SZ, _P]),
     "effq_admm_project_dual": (_I, [_P, _P, _P, _I, _P, _P, _F, _P, _SZ, _P]),
     "effq_conv_i8_supported": (_I, [_GP, _I, _I]),
+    "effq_conv_i8s_supported": (_I, [_GP, _I, _I]),
+    "effq_conv_i8s_ws_bytes": (_SZ, [_GP, _I, _I]),
+    "conv3d_calib_step_i8s": (_I, [_P, _P, _P, _P, _GP, _P, _I, _P, _I, _I, _P, _P, _SZ, _P]),
     "effq_conv_i8_ws_bytes": (_SZ, [_GP]),
     "conv3d_calib_step_i8": (_I, [_P, _P, _P, _P, _GP, _P, _I, _P, _I, _P, _P, _SZ, _P]),
     "effq_admm_keep_best": (_I, [_P, _P, _I, _P, _P, _P, _P, _SZ, _SZ, _P]),

@@ -13,6 +13,7 @@
 // is one coalesced 16-byte load per lane straight from L2 (shared by every workgroup).
 #include <stdlib.h>
 #include "common.h"
+#include "conv_direct.h"
 
 namespace effq {
 
@@ -631,8 +632,10 @@ static int make_plan(const effq_geom* g, ConvPlan* pl) {
   return EFFQ_OK;
 }
 
+constexpr size_t DIRECT_MAX_BLOCKS = 2048;   // partial-sum slots kept for the direct kernels (conv3d_direct.hip)
+static size_t conv_partial_slots(const ConvPlan& pl) { return pl.nblk > DIRECT_MAX_BLOCKS ? pl.nblk : DIRECT_MAX_BLOCKS; }
 static size_t conv_ws_bytes(const ConvPlan& pl) {
-  return 256 + pl.nblk * 2 * sizeof(double) + pl.wp_floats * sizeof(float) + 256;
+  return 256 + conv_partial_slots(pl) * 2 * sizeof(double) + pl.wp_floats * sizeof(float) + 256;
 }
 
 }  // namespace effq
@@ -665,7 +668,7 @@ int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* 
   ConvParams& p = pl.p;
   p.ticket = reinterpret_cast<unsigned int*>(base);
   p.partials = reinterpret_cast<double*>(base + 256);
-  float* wp = reinterpret_cast<float*>(base + 256 + pl.nblk * 2 * sizeof(double));
+  float* wp = reinterpret_cast<float*>(base + 256 + conv_partial_slots(pl) * 2 * sizeof(double));
   // 16-byte alignment of the packed weights
   wp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wp) + 15) & ~(uintptr_t)15);
   p.x = xq_ndhwc;
@@ -684,6 +687,24 @@ int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* 
   }
   hipStream_t st = as_stream(stream);
   if (y_fp != nullptr) EFFQ_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned int), st));
+  // loss-only calls of the short-K layers go to the direct-gather kernels
+  const int dkind = (out == nullptr && att == nullptr && !p.act_on && y_fp != nullptr && getenv("EFFQ_NO_DIRECT") == nullptr)
+                        ? conv_direct_kind(g) : 0;
+  if (dkind != 0) {
+    DirectParams dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.x = xq_ndhwc; dp.G = G; dp.bias = bias; dp.y = y_fp;
+    dp.N = p.N; dp.C1 = p.C1; dp.C2 = p.C2; dp.D = p.D; dp.H = p.H; dp.W = p.W;
+    dp.OD = p.OD; dp.OH = p.OH; dp.OW = p.OW; dp.SD = p.SD; dp.SH = p.SH; dp.SW = p.SW;
+    dp.PD = p.PD; dp.PH = p.PH; dp.PW = p.PW;
+    dp.V = (long long)p.N * p.OD * p.OH * p.OW;
+    dp.partials = p.partials; dp.ticket = p.ticket; dp.sqerr = sqerr_out;
+    rc = conv_direct_launch(dkind, dp, DIRECT_MAX_BLOCKS, st);
+    if (rc == EFFQ_OK) {
+      EFFQ_LAUNCH_CHECK();
+      return EFFQ_OK;
+    }
+  }
   {
     size_t nb = (pl.wp_floats + 255) / 256;
     if (nb > 4096) nb = 4096;

@@ -1,0 +1,170 @@
+// Direct-gather fp32 loss convs for the two layers the tiled kernels serve badly (conv3d_quant_calib_step picks
+// them when only the loss is wanted: no output tensor, no attention weights, input already quantised or raw):
+//   * k_conv3d_c4: C1 == 4, 3x3x3 taps, any stride/padding, C2 == 32 - the first conv of the 3D-UNets
+//     (4 MRI modalities -> 32 channels, stride 2: config/brats_ptq.yaml; EfficientQConv.py:118-122).  K = 108 is
+//     too short for channel-slab LDS tiling; here one wave owns 32 consecutive output voxels, its 54 B operands
+//     (27 taps x 2 K steps of v_mfma_f32_32x32x2_f32) sit in registers for the whole kernel and each lane gathers
+//     the two channels it feeds (8 bytes per tap) straight from L2 - no LDS, latency covered by occupancy.
+//   * k_conv1_small: 1x1x1 convs onto at most 4 output channels - the classifier (32 -> 3).  HBM-bound: LPV = C1/4
+//     lanes share a voxel (one coalesced 16-byte load each), partial dot products are reduced with DPP shuffles.
+// Both end in the deterministic last-block reduction of common.h and write [sum d^2, sum d^2] like the tiled path.
+#include <stdint.h>
+#include "common.h"
+#include "conv_direct.h"
+
+namespace effq {
+
+typedef float d_f32x16 __attribute__((ext_vector_type(16)));
+typedef float d_f32x2 __attribute__((ext_vector_type(2)));
+typedef float d_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_conv3d_c4(DirectParams p) {
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  constexpr int T = 27;
+
+  // B operands: K index of MFMA (tap, e) on lane half lh is channel 2*lh + e of that tap
+  float breg[T][2];
+#pragma unroll
+  for (int tap = 0; tap < T; ++tap)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) breg[tap][e] = p.G[((size_t)li * 4 + 2 * lh + e) * T + tap];   // G [C2][C1][T]
+  const float bv = (p.bias != nullptr) ? p.bias[li] : 0.0f;
+
+  double l0 = 0.0;
+  const int wave_global = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
+  for (int tile = wave_global; tile < p.ntiles; tile += nwaves) {
+    const long long v = (long long)tile * 32 + li;
+    const bool vvalid = v < p.V;
+    int t = (int)(vvalid ? v : 0);
+    const int ow = t % p.OW;
+    t /= p.OW;
+    const int oh = t % p.OH;
+    t /= p.OH;
+    const int od = t % p.OD;
+    const int n = t / p.OD;
+    const int id0 = od * p.SD - p.PD, ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
+    unsigned wm = 0, hm = 0, dm = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      wm |= (unsigned)(iw0 + k >= 0 && iw0 + k < p.W) << k;
+      hm |= (unsigned)(ih0 + k >= 0 && ih0 + k < p.H) << k;
+      dm |= (unsigned)(id0 + k >= 0 && id0 + k < p.D) << k;
+    }
+    if (!vvalid) dm = 0;
+    const int xbase = (((n * p.D + id0) * p.H + ih0) * p.W + iw0) * 4 + 2 * lh;
+
+    // targets first (independent of everything else), then the 27 gathers, then the MFMA chain
+    const long long v0 = (long long)tile * 32;
+    float yv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long vr = v0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      yv[r] = p.y[(vr < p.V ? vr : 0) * 32 + li];
+    }
+    d_f32x2 xv[T];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const bool ok = ((dm >> kd) & (hm >> kh) & (wm >> kw) & 1u) != 0;
+          const int addr = ok ? (xbase + ((kd * p.H + kh) * p.W + kw) * 4) : 0;
+          const d_f32x2 raw = *reinterpret_cast<const d_f32x2*>(p.x + addr);
+          xv[(kd * 3 + kh) * 3 + kw] = ok ? raw : d_f32x2{0.0f, 0.0f};
+        }
+    d_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[tap][0], breg[tap][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[tap][1], breg[tap][1], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long vr = v0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (vr < p.V) {
+        const float d = (acc[r] + bv) - yv[r];
+        l0 += (double)d * (double)d;
+      }
+    }
+  }
+  double vsum[2] = {l0, l0};
+  grid_sum_finish<2>(vsum, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
+}
+
+// 1x1x1 conv onto C2 <= 4 channels: LPV lanes per voxel, each owns 4 input channels
+template <int LPV>
+__global__ __launch_bounds__(256) void k_conv1_small(DirectParams p) {
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  const int sub = tid % LPV;            // channel quad of this lane
+  constexpr int VPB = 256 / LPV;        // voxels per block pass
+  float w[4][4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[o][j] = (o < p.C2) ? p.G[(size_t)o * p.C1 + 4 * sub + j] : 0.0f;
+  float bv[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) bv[o] = (p.bias != nullptr && o < p.C2) ? p.bias[o] : 0.0f;
+
+  double l0 = 0.0;
+  const long long stride = (long long)gridDim.x * VPB;
+  for (long long v = (long long)blockIdx.x * VPB + tid / LPV; v < p.V; v += stride) {
+    const d_f32x4 xv = *reinterpret_cast<const d_f32x4*>(p.x + v * p.C1 + 4 * sub);
+    float s[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) s[o] = ((xv[0] * w[o][0] + xv[1] * w[o][1]) + xv[2] * w[o][2]) + xv[3] * w[o][3];
+#pragma unroll
+    for (int m = 1; m < LPV; m <<= 1)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) s[o] += __shfl_xor(s[o], m);
+    if (sub == 0) {
+      for (int o = 0; o < p.C2; ++o) {
+        const float d = (s[o] + bv[o]) - p.y[v * p.C2 + o];
+        l0 += (double)d * (double)d;
+      }
+    }
+  }
+  double vsum[2] = {l0, l0};
+  grid_sum_finish<2>(vsum, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
+}
+
+int conv_direct_kind(const effq_geom* g) {
+  if (g->C1 == 4 && g->C2 == 32 && g->KD == 3 && g->KH == 3 && g->KW == 3) return 1;
+  if (g->KD == 1 && g->KH == 1 && g->KW == 1 && g->SD == 1 && g->SH == 1 && g->SW == 1 && g->PD == 0 && g->PH == 0 &&
+      g->PW == 0 && g->C2 <= 4 && (g->C1 == 32 || g->C1 == 64 || g->C1 == 128 || g->C1 == 256))
+    return 2;
+  return 0;
+}
+
+int conv_direct_launch(int kind, DirectParams& p, size_t max_blocks, hipStream_t st) {
+  if ((long long)p.N * p.D * p.H * p.W * p.C1 >= (1ll << 31) || p.V >= (1ll << 31)) return EFFQ_ERR_ARG;
+  p.ntiles = (int)((p.V + 31) / 32);
+  if (kind == 1) {
+    size_t grid = ((size_t)p.ntiles + 3) / 4;
+    if (grid > 768) grid = 768;               // 3 workgroups (12 waves) per CU, grid-stride over the tiles
+    if (grid > max_blocks) grid = max_blocks;
+    hipLaunchKernelGGL(k_conv3d_c4, dim3((unsigned)grid), dim3(256), 0, st, p);
+    return EFFQ_OK;
+  }
+  const int lpv = p.C1 / 4;
+  size_t grid = ((size_t)p.V * lpv + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  if (grid > max_blocks) grid = max_blocks;
+  switch (lpv) {
+    case 8: hipLaunchKernelGGL(k_conv1_small<8>, dim3((unsigned)grid), dim3(256), 0, st, p); break;
+    case 16: hipLaunchKernelGGL(k_conv1_small<16>, dim3((unsigned)grid), dim3(256), 0, st, p); break;
+    case 32: hipLaunchKernelGGL(k_conv1_small<32>, dim3((unsigned)grid), dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL(k_conv1_small<64>, dim3((unsigned)grid), dim3(256), 0, st, p); break;
+  }
+  return EFFQ_OK;
+}
+
+}  // namespace effq

@@ -454,7 +454,9 @@ __global__ __launch_bounds__(TPB) void k_project_dual(const float* __restrict__ 
     float b = (float)disc64((double)v[i], alpha, -1.0, 1.0, d, &r);
     float g = alpha32 * b;
     G[i] = g;
-    if (Gq != nullptr) Gq[i] = (int8_t)(2 * (int)r - lm1);   // signed level numerator j' = 2*level - (L-1)
+    // int8 operand of the exact-integer convs: the signed numerator j' = 2*level - (L-1), or, beyond 128
+    // levels where that no longer fits, level - 128 (conv3d_i8s.hip rebuilds j' = 2*(level-128) + 1)
+    if (Gq != nullptr) Gq[i] = (lm1 >= 128) ? (int8_t)((int)r - 128) : (int8_t)(2 * (int)r - lm1);
     float du = (wstar[i] - g) + dual[i];        // EfficientQConv.py:111
     if (dual_div != 1.0f) du = du / dual_div;   // "dual /= 2" or "dual /= rho_m/rho" (:131-136)
     dual[i] = du;
@@ -663,7 +665,7 @@ int effq_admm_presum(const float* wstar, const float* dual, float* v, size_t n, 
 int effq_admm_project_dual(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
                            float* dual, float dual_div, int8_t* Gq_out, size_t n, void* stream) {
   EFFQ_CHECK_ARG(v && wstar && state_dev && G && dual && levels >= 2 && dual_div > 0.0f);
-  EFFQ_CHECK_ARG(Gq_out == nullptr || levels <= 128);
+  EFFQ_CHECK_ARG(Gq_out == nullptr || levels <= 256);
   if (n == 0) return EFFQ_OK;
   const double d = 2.0 / (double)(levels - 1);
   hipLaunchKernelGGL(k_project_dual, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,

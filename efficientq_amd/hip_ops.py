@@ -331,6 +331,25 @@ class HipOps:
     def conv_i8_supported(self, geom: Geom, act_levels: int, w_levels: int) -> bool:
         return bool(self.lib.effq_conv_i8_supported(C.byref(geom), int(act_levels), int(w_levels)))
 
+    def conv_i8s_supported(self, geom: Geom, act_levels: int, w_levels: int) -> bool:
+        return bool(self.lib.effq_conv_i8s_supported(C.byref(geom), int(act_levels), int(w_levels)))
+
+    def conv_step_i8s(self, xidx: torch.Tensor, Gq: torch.Tensor, bias, geom: Geom, y_ndhwc: torch.Tensor,
+                      act_alpha: torch.Tensor, act_levels: int, w_state: torch.Tensor, w_levels: int, sqerr,
+                      prepare: bool):
+        """Exact-integer loss evaluation for short-K layers and up to 256 levels (conv3d_calib_step_i8s).
+        prepare=True on the first call of a layer (per-voxel level sums are cached in the workspace)."""
+        if xidx.dtype != torch.uint8 or Gq.dtype != torch.int8:
+            raise _lib.EffqError("conv_step_i8s wants uint8 level ids and int8 weight operands")
+        _check_shapes(geom, xidx, Gq, bias, y_ndhwc)
+        al = self._f32(act_alpha.reshape(1))
+        ws = self._workspace("conv_i8s", self.lib.effq_conv_i8s_ws_bytes(C.byref(geom), int(act_levels), int(w_levels)))
+        check(self.lib.conv3d_calib_step_i8s(_ptr(xidx), _ptr(Gq), _ptr(bias), _ptr(self._f32(y_ndhwc)),
+                                             C.byref(geom), _ptr(al), int(act_levels), _ptr(w_state), int(w_levels),
+                                             int(bool(prepare)), _ptr(sqerr), _ptr(ws), ws.numel(), self.stream),
+              "conv3d_calib_step_i8s")
+        return sqerr
+
     def conv_step_i8(self, xidx: torch.Tensor, Gq: torch.Tensor, bias, geom: Geom, y_ndhwc: torch.Tensor,
                      act_alpha: torch.Tensor, act_levels: int, w_state: torch.Tensor, w_levels: int, sqerr):
         """Exact-integer loss evaluation (conv3d_calib_step_i8)."""

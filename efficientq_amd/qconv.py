@@ -236,6 +236,10 @@ class EfficientQConvHIP(PTQConv):
         # exact-integer evaluation of the 200 per-iteration losses (north_star's "int-simulated" forward)
         use_i8 = bool(self.q_act and not self._act_inited and self.lwq_exact_int and
                       getattr(ops, "conv_i8_supported", lambda *a: False)(geom, self.qlvl_act, self.qlvl_w))
+        # ... through the direct-gather kernel for short-K layers and the 256-level first/last layers
+        use_i8s = bool((not use_i8) and self.q_act and not self._act_inited and self.lwq_exact_int and
+                       getattr(ops, "conv_i8s_supported", lambda *a: False)(geom, self.qlvl_act, self.qlvl_w))
+        int_conv = use_i8 or use_i8s
         # ... and of the Gram system (exact integer sums, weights applied per attention class)
         use_gi8 = bool(self.q_act and not self._act_inited and self.lwq_exact_int and
                        getattr(ops, "gram_i8_supported", lambda *a: False)(geom, self.qlvl_act))
@@ -248,7 +252,7 @@ class EfficientQConvHIP(PTQConv):
                 a_act, act_iters, st = ops.fit_scale(xn, self.qlvl_act, 0.0, 1.0, reducer=red or None,
                                                      guess_iters=12 * self.qlvl_act)
                 self.alpha_act.data = torch.tensor(a_act, dtype=x.dtype, device=dev)
-                xq, _, xidx = ops.quant_dequant_f64path(xn, st, self.qlvl_act, 0.0, 1.0, want_idx=use_i8 or use_gi8)
+                xq, _, xidx = ops.quant_dequant_f64path(xn, st, self.qlvl_act, 0.0, 1.0, want_idx=int_conv or use_gi8)
         else:
             xq = xn
 
@@ -278,7 +282,7 @@ class EfficientQConvHIP(PTQConv):
         sqerr = torch.zeros(2, dtype=torch.float64, device=dev)
         best = torch.zeros(2, dtype=torch.float64, device=dev)
         stb = [ops.new_fp_state(), ops.new_fp_state()]
-        Gqb = [torch.empty(W0.shape, dtype=torch.int8, device=dev) for _ in range(2)] if use_i8 else [None, None]
+        Gqb = [torch.empty(W0.shape, dtype=torch.int8, device=dev) for _ in range(2)] if int_conv else [None, None]
         fp_err = torch.zeros(1, dtype=torch.int32, device=dev)
         loss_s = getattr(ops, "loss_stream", lambda: None)() if self.lwq_overlap_loss else None
         main_s = torch.cuda.current_stream(dev) if loss_s is not None else None
@@ -329,7 +333,7 @@ class EfficientQConvHIP(PTQConv):
             dual_div = 1.0
             if i % RHO_PERIOD == 0:                                        # (:129-137)
                 dual_div = 2.0 if rho * 2 <= rho_m else rho_m / rho
-            if use_i8:
+            if int_conv:
                 ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div, Gq)
             else:
                 ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div)
@@ -338,6 +342,9 @@ class EfficientQConvHIP(PTQConv):
                 if use_i8:
                     ops.conv_step_i8(xidx, Gq, bstar, geom, yn, self.alpha_act.data, self.qlvl_act, st_w,
                                      self.qlvl_w, sqerr)
+                elif use_i8s:
+                    ops.conv_step_i8s(xidx, Gq, bstar, geom, yn, self.alpha_act.data, self.qlvl_act, st_w,
+                                      self.qlvl_w, sqerr, i == 0)
                 else:
                     ops.conv_step(xq, G, bstar, geom, yn, None, sqerr=sqerr)   # unweighted MSE (quirk Q5)
                 red(sqerr)
@@ -382,7 +389,7 @@ class EfficientQConvHIP(PTQConv):
         self.last_trace = dict(rho_scale=rho_scale, best_iter=int(best_h[1]), best_mse=best_h[0] / numel,
                                final_mse=fin_h[0] / numel, layer_loss=lossf, act_iters=act_iters,
                                w_iters=w_iters, alpha_w=a_w, loss_history=[h / numel for h in hist],
-                               exact_int=use_i8, exact_gram=use_gi8, host_enqueue_s=t_enq, admm_loop_s=t_loop)
+                               exact_int=int_conv, exact_gram=use_gi8, host_enqueue_s=t_enq, admm_loop_s=t_loop)
 
     def compute_quant_error(self, output_fp, Qw, Qact):
         """EfficientQConv.py:168-172."""

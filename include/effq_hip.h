@@ -202,6 +202,19 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
                          const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, void* ws,
                          size_t ws_bytes, void* stream);
 
+/* The same exact-integer loss for the layers the tiled kernels above do not take: few taps*channels
+ * (KD*KH*KW*C1 <= 256 with C1 == 4 or C1 % 16 == 0: the first conv, the 1x1x1 convs, the classifier), any
+ * stride/padding, and up to 256 levels on either side (q_first/q_last = 256 in the reference's recipes).
+ * Gq holds the int8 operands effq_admm_project_dual emits (2*level-(Lw-1), or level-128 when Lw > 128).
+ * prepare != 0 (first call of a layer) also rebuilds the per-voxel level sums the Lw > 128 form needs; they
+ * live in ws between calls.  ws: effq_conv_i8s_ws_bytes(geom, act_levels, w_levels). */
+int effq_conv_i8s_supported(const effq_geom* g, int act_levels, int w_levels);
+size_t effq_conv_i8s_ws_bytes(const effq_geom* g, int act_levels, int w_levels);
+int conv3d_calib_step_i8s(const uint8_t* xidx_ndhwc, const int8_t* Gq, const float* bias, const float* y_fp,
+                          const effq_geom* g, const float* act_alpha_dev, int act_levels,
+                          const effq_fp_state* w_state_dev, int w_levels, int prepare, double* sqerr_out,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* ---- f3 (next row): Adam step for tune_activation_range (ptqer.py:238-272) ---- */
 int effq_adam_step(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
                    int t, size_t n, void* stream);
