@@ -76,6 +76,7 @@ SIGNATURES = {
     "effq_spd_inverse": (_I, [_P, _I, _I, _D, _D, _P, _P, _SZ, _P]),
     "effq_prox_ws_bytes": (_SZ, [_I, _I]),
     "effq_prox_solve": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _D, _D, _P, _P, _P, _SZ, _P]),
+    "effq_prox_solve_shifted": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _D, _D, _D, _I, _P, _P, _P, _SZ, _P]),
     "effq_admm_presum": (_I, [_P, _P, _P, _SZ, _P]),
     "effq_admm_project_dual": (_I, [_P, _P, _P, _I, _P, _P, _F, _P, _SZ, _P]),
     "effq_conv_i8_supported": (_I, [_GP, _I, _I]),

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void k_a64_to_f32(const double* __restrict__ A
 __global__ __launch_bounds__(256) void k_build_b(const float* __restrict__ B0, const float* __restrict__ W0,
                                                  const float* __restrict__ b0, const float* __restrict__ G,
                                                  const float* __restrict__ dual, int c2, int n, int has_bias,
-                                                 float rho, float eta, float* __restrict__ Bm, int ldb, int c2p) {
+                                                 float rho, float eta, float* __restrict__ Bm, int ldb, int c2p,
+                                                 const float* __restrict__ wprev, float shift) {
   const size_t tot = (size_t)c2p * ldb;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const int nw = n - has_bias;
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256) void k_build_b(const float* __restrict__ B0, c
         const size_t wi = (size_t)r * nw + k;
         v = B0[(size_t)r * n + k] + eta * W0[wi];
         v = v + rho * (G[wi] - dual[wi]);
+        if (wprev != nullptr) v = v + shift * wprev[wi];     // effq_prox_solve_shifted: + d * W_prev * I'
       } else {
         v = B0[(size_t)r * n + k] + eta * b0[r];
       }
@@ -505,10 +507,10 @@ size_t effq_prox_ws_bytes(int c2, int n) {
   return ((size_t)p.c2p + (p.nsplit > 1 ? (size_t)p.nsplit * c2 : 0)) * p.ldb * sizeof(float) + 256;
 }
 
-int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
-                    const float* dual, int c2, int n, int has_bias, double rho, double eta, float* wstar, float* bstar,
-                    void* ws, size_t ws_bytes, void* stream) {
-  EFFQ_CHECK_ARG(B0 && Ainv && W0 && G && dual && wstar && ws && c2 > 0 && n > 0);
+static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
+                           const float* dual, int c2, int n, int has_bias, double rho, double eta, double shift,
+                           int nterms, float* wstar, float* bstar, void* ws, size_t ws_bytes, void* stream) {
+  EFFQ_CHECK_ARG(B0 && Ainv && W0 && G && dual && wstar && ws && c2 > 0 && n > 0 && nterms >= 1);
   EFFQ_CHECK_ARG(!has_bias || (b0 != nullptr && bstar != nullptr));
   if (ws_bytes < effq_prox_ws_bytes(c2, n)) {
     set_error("prox_solve: workspace %zu < required %zu", ws_bytes, effq_prox_ws_bytes(c2, n));
@@ -521,33 +523,50 @@ int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const f
   float* Bm = reinterpret_cast<float*>(ws);
   float* part = Bm + (size_t)c2p * ldb;
   hipStream_t st = as_stream(stream);
-  {
-    size_t nb = ((size_t)c2p * ldb + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(k_build_b, dim3((unsigned)nb), dim3(256), 0, st, B0, W0, b0, G, dual, c2, n, has_bias ? 1 : 0,
-                       (float)rho, (float)eta, Bm, ldb, c2p);
-    EFFQ_LAUNCH_CHECK();
-  }
-  const dim3 grid(pl.gx, pl.gy, pl.nsplit);
+  for (int term = 0; term < nterms; ++term) {
+    {
+      size_t nb = ((size_t)c2p * ldb + 255) / 256;
+      if (nb > 4096) nb = 4096;
+      hipLaunchKernelGGL(k_build_b, dim3((unsigned)nb), dim3(256), 0, st, B0, W0, b0, G, dual, c2, n, has_bias ? 1 : 0,
+                         (float)rho, (float)eta, Bm, ldb, c2p, (term > 0) ? wstar : nullptr, (float)shift);
+      EFFQ_LAUNCH_CHECK();
+    }
+    const dim3 grid(pl.gx, pl.gy, pl.nsplit);
 #define EFFQ_PROX_LAUNCH(MT, WM, WN, NTN)                                                                              \
   hipLaunchKernelGGL((k_prox_gemm<MT, WM, WN, NTN>), grid, dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2, has_bias ? 1 : 0, \
                      wstar, bstar, part, ldb)
-  switch (pl.variant) {
-    case 0: EFFQ_PROX_LAUNCH(2, 4, 1, 2); break;
-    case 1: EFFQ_PROX_LAUNCH(1, 4, 1, 2); break;
-    case 2: EFFQ_PROX_LAUNCH(1, 2, 2, 1); break;
-    default: EFFQ_PROX_LAUNCH(1, 1, 4, 1); break;
-  }
+    switch (pl.variant) {
+      case 0: EFFQ_PROX_LAUNCH(2, 4, 1, 2); break;
+      case 1: EFFQ_PROX_LAUNCH(1, 4, 1, 2); break;
+      case 2: EFFQ_PROX_LAUNCH(1, 2, 2, 1); break;
+      default: EFFQ_PROX_LAUNCH(1, 1, 4, 1); break;
+    }
 #undef EFFQ_PROX_LAUNCH
-  EFFQ_LAUNCH_CHECK();
-  if (pl.nsplit > 1) {
-    size_t nb = ((size_t)c2 * ldb + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_prox_reduce, dim3((unsigned)nb), dim3(256), 0, st, part, ldb, pl.nsplit, c2, n, has_bias ? 1 : 0,
-                       wstar, bstar);
+    EFFQ_LAUNCH_CHECK();
+    if (pl.nsplit > 1) {
+      size_t nb = ((size_t)c2 * ldb + 255) / 256;
+      if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(k_prox_reduce, dim3((unsigned)nb), dim3(256), 0, st, part, ldb, pl.nsplit, c2, n,
+                         has_bias ? 1 : 0, wstar, bstar);
+      EFFQ_LAUNCH_CHECK();
+    }
   }
-  EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
+}
+
+int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
+                    const float* dual, int c2, int n, int has_bias, double rho, double eta, float* wstar, float* bstar,
+                    void* ws, size_t ws_bytes, void* stream) {
+  return prox_solve_impl(B0, Ainv, W0, b0, G, dual, c2, n, has_bias, rho, eta, 0.0, 1, wstar, bstar, ws, ws_bytes,
+                         stream);
+}
+
+int effq_prox_solve_shifted(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
+                            const float* dual, int c2, int n, int has_bias, double rho, double eta, double rho_inv,
+                            int nterms, float* wstar, float* bstar, void* ws, size_t ws_bytes, void* stream) {
+  EFFQ_CHECK_ARG(rho_inv >= rho && rho > 0.0 && eta >= 0.0);
+  return prox_solve_impl(B0, Ainv, W0, b0, G, dual, c2, n, has_bias, rho, eta, rho_inv - rho, nterms, wstar, bstar, ws,
+                         ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@ No CPU fallback exists here on purpose: tensors must live on a HIP device.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Optional, Tuple
 
 import torch
@@ -317,6 +318,20 @@ class HipOps:
         check(self.lib.effq_prox_solve(_ptr(B0), _ptr(Ainv), _ptr(W0), _ptr(b0), _ptr(G), _ptr(dual), c2, n,
                                        int(b0 is not None), rho, eta, _ptr(wstar), _ptr(bstar), _ptr(ws),
                                        ws.numel(), self.stream), "effq_prox_solve")
+
+    PROX_SHIFT_TERMS = 26      # contraction factor < 1/2 per sweep: 2^-26 is below fp32 resolution
+
+    def prox_solve_shifted(self, B0, Ainv, W0, b0, G, dual, rho: float, eta: float, rho_inv: float, wstar, bstar):
+        """prox_solve for A(rho) through the inverse of A(rho_inv), rho_inv >= rho (effq_prox_solve_shifted)."""
+        c2, n = B0.shape
+        ws = self._workspace("prox", self.lib.effq_prox_ws_bytes(c2, n))
+        # sweeps for 2^-26: factor <= d/(rho_inv+eta)
+        d = rho_inv - rho
+        terms = 1 if d <= 0 else min(64, max(2, int(math.ceil(-26.0 * math.log(2.0) / math.log(d / (rho_inv + eta))))))
+        check(self.lib.effq_prox_solve_shifted(_ptr(B0), _ptr(Ainv), _ptr(W0), _ptr(b0), _ptr(G), _ptr(dual), c2, n,
+                                               int(b0 is not None), rho, eta, rho_inv, terms, _ptr(wstar),
+                                               _ptr(bstar), _ptr(ws), ws.numel(), self.stream),
+              "effq_prox_solve_shifted")
 
     # -- a4 elementwise -------------------------------------------------------------------------
     def admm_presum(self, wstar, dual, v):

@@ -296,12 +296,16 @@ class EfficientQConvHIP(PTQConv):
                 rhos.append(r_)
             if i % RHO_PERIOD == 0:
                 r_ = r_ * 2 if r_ * 2 <= rho_m else rho_m
-        inv_of = {rhos[0]: (ops.spd_inverse(A0, has_b, rhos[0], eta), None)}
+        # rhos[0] serves iteration 0 only (the schedule doubles right after it): no inverse is formed for it,
+        # its solve runs as fixed-point sweeps through the inverse of A(rhos[1]) (effq_prox_solve_shifted)
+        shifted_first = len(rhos) > 1 and rhos[1] > rhos[0] and hasattr(ops, "prox_solve_shifted")
+        first = 1 if shifted_first else 0
+        inv_of = {rhos[first]: (ops.spd_inverse(A0, has_b, rhos[first], eta), None)}
         side = getattr(ops, "side_stream", lambda: None)()
-        if side is not None and len(rhos) > 1:
+        if side is not None and len(rhos) > first + 1:
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                for r_ in rhos[1:]:
+                for r_ in rhos[first + 1:]:
                     buf = ops.spd_inverse(A0, has_b, r_, eta, ws_key="inv_side")
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -313,7 +317,8 @@ class EfficientQConvHIP(PTQConv):
         a_w = 1.0
         w_iters, hist = [], []
         for i in range(self.lwq_iter):                                     # (:99-144)
-            if rho_of_inv != rho:      # A changes only with rho: 5 inverses per layer, not 200 LU solves
+            use_shift = shifted_first and i == 0
+            if rho_of_inv != rho and not use_shift:   # A changes only with rho: 4 inverses per layer, not 200 LU solves
                 if rho not in inv_of:
                     inv_of[rho] = (ops.spd_inverse(A0, has_b, rho, eta), None)
                 Ainv, ev = inv_of[rho]
@@ -324,7 +329,10 @@ class EfficientQConvHIP(PTQConv):
             if ev_loss[p_] is not None:             # the loss of iteration i-2 is done with this parity's buffers
                 main_s.wait_event(ev_loss[p_])
             G, Gq, bstar, st_w = Gb[p_], Gqb[p_], bsb[p_], stb[p_]
-            ops.prox_solve(B0, Ainv, W0, b0, Gb[p_ ^ 1], dual, rho, eta, wstar, bstar)
+            if use_shift:
+                ops.prox_solve_shifted(B0, inv_of[rhos[1]][0], W0, b0, Gb[p_ ^ 1], dual, rho, eta, rhos[1], wstar, bstar)
+            else:
+                ops.prox_solve(B0, Ainv, W0, b0, Gb[p_ ^ 1], dual, rho, eta, wstar, bstar)
             it_w = ops.weight_fixed_point(wstar, dual, v, self.qlvl_w, st_w, guess)   # (:108) no host sync
             ops.fp_check(st_w, fp_err)                                                # when the tensor is small
             if it_w is not None:

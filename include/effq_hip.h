@@ -161,6 +161,15 @@ int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const f
                     const float* dual, int c2, int n, int has_bias, double rho, double eta, float* wstar,
                     float* bstar, void* ws, size_t ws_bytes, void* stream);
 
+/* The same solve for A(rho) when only Ainv = A(rho_inv)^-1 is at hand (rho_inv >= rho): A(rho) = A(rho_inv) -
+ * d*I' with d = rho_inv - rho, so What = (B + d*[What_w|0]) * Ainv is a contraction with factor
+ * < d/(rho_inv + eta) (1/2 for the reference's doubling schedule, EfficientQConv.py:129-137).  nterms sweeps of
+ * the GEMM; 26 reach fp32 resolution.  Used for iteration 0, whose rho serves that one iteration only. */
+int effq_prox_solve_shifted(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
+                            const float* dual, int c2, int n, int has_bias, double rho, double eta,
+                            double rho_inv, int nterms, float* wstar, float* bstar, void* ws, size_t ws_bytes,
+                            void* stream);
+
 /* ---- a4: ADMM elementwise steps (EfficientQConv.py:108-111,129-137,139-142) ----
  * v = wstar + dual                                  (input of the weight projection) */
 int effq_admm_presum(const float* wstar, const float* dual, float* v, size_t n, void* stream);

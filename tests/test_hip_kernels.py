@@ -260,6 +260,16 @@ def test_spd_inverse_and_prox(ops, n, c2):
     wantW = torch.linalg.solve(A, Bm.T).T
     got = torch.cat([wstar.cpu(), bstar.cpu()[:, None]], 1).double()
     assert (got - wantW).abs().max() <= 2e-5 * wantW.abs().max()
+    # the solve for rho/2 through the SAME inverse (effq_prox_solve_shifted: iteration 0 of the ADMM schedule,
+    # whose rho doubles right after it) equals the direct solve of that system
+    rho0 = rho / 2
+    A_half = A - torch.diag(torch.cat([torch.full((n - 1,), rho - rho0, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)]))
+    Bm0 = B0.double() + eta * torch.cat([W0, b0[:, None]], 1).double()
+    Bm0[:, :-1] += rho0 * (G - dual).double()
+    want0 = torch.linalg.solve(A_half, Bm0.T).T
+    ops.prox_solve_shifted(dev(B0), Ainv_pad, dev(W0), dev(b0), dev(G), dev(dual), rho0, eta, rho, wstar, bstar)
+    got0 = torch.cat([wstar.cpu(), bstar.cpu()[:, None]], 1).double()
+    assert (got0 - want0).abs().max() <= 3e-5 * want0.abs().max()
 
 
 # ------------------------------------------------------------------ the conv entry point
