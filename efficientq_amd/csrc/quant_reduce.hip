@@ -337,6 +337,8 @@ __global__ __launch_bounds__(FPC_T) void k_fp_coop(const float* __restrict__ a, 
                                                    unsigned int* counter) {
   extern __shared__ __attribute__((aligned(16))) float vs[];      // this workgroup's slice of v
   __shared__ double smem[2 * 16];
+  __shared__ double s_part[2 * FPC_MAXG];
+  __shared__ double s_tot[2];
   __shared__ int s_fail;
   const int tid = threadIdx.x, G = gridDim.x, wg = blockIdx.x;
   const size_t per = (n + G - 1) / G;
@@ -353,13 +355,39 @@ __global__ __launch_bounds__(FPC_T) void k_fp_coop(const float* __restrict__ a, 
   block_sum<2>(acc, smem);
   unsigned epoch = 0;
   // partials layout: [parity][wg][2]
-  if (tid == 0) partials[(0 * FPC_MAXG + wg) * 2 + 0] = acc[0];
+  if (tid == 0) {
+    partials[(0 * FPC_MAXG + wg) * 2 + 0] = acc[0];
+    partials[(0 * FPC_MAXG + wg) * 2 + 1] = 0.0;
+  }
   if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail)) {
     if (wg == 0 && tid == 0) st->done = 3;
     return;
   }
-  double tot = 0.0;
-  for (int g = 0; g < G; ++g) tot += __hip_atomic_load(&partials[(0 * FPC_MAXG + g) * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the G partials are fetched by G lanes (one agent-scope load each), added by ONE thread in workgroup order
+  // (identical value in every workgroup, run to run) and broadcast through LDS -- every thread re-reading
+  // all G partials costs 2*G*1024 uncached loads per workgroup per iteration and dominated the iteration
+  auto combine = [&](int par, double& t0, double& t1) {
+    if (tid < G) {
+      s_part[tid] = __hip_atomic_load(&partials[(par * FPC_MAXG + tid) * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_part[FPC_MAXG + tid] = __hip_atomic_load(&partials[(par * FPC_MAXG + tid) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double u0 = 0.0, u1 = 0.0;
+      for (int g = 0; g < G; ++g) {
+        u0 += s_part[g];
+        u1 += s_part[FPC_MAXG + g];
+      }
+      s_tot[0] = u0;
+      s_tot[1] = u1;
+    }
+    __syncthreads();
+    t0 = s_tot[0];
+    t1 = s_tot[1];
+    __syncthreads();
+  };
+  double tot = 0.0, tdummy = 0.0;
+  combine(0, tot, tdummy);
   double alpha = tot / (double)n, alpha_prev = -999.0;
   int it = 0, done = 0;
   double last0 = 0.0, last1 = 0.0;
@@ -384,10 +412,7 @@ __global__ __launch_bounds__(FPC_T) void k_fp_coop(const float* __restrict__ a, 
       return;
     }
     double t0 = 0.0, t1 = 0.0;
-    for (int g = 0; g < G; ++g) {
-      t0 += __hip_atomic_load(&partials[(par * FPC_MAXG + g) * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      t1 += __hip_atomic_load(&partials[(par * FPC_MAXG + g) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    combine(par, t0, t1);
     const double a_new = t0 / t1;
     alpha_prev = alpha;
     ++it;
