@@ -29,6 +29,9 @@ def loss():
     ops.conv_step_i8(xidx, Gq, bstar, geom, y, alpha, 4, st, 4, sq)
 
 def make_stream(sel):
+    if mask_chain < 0:      # stream priorities: chain high, loss low
+        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        return torch.cuda.Stream(dev, priority=(hi if sel == "chain" else lo))
     if not mask_chain:
         return torch.cuda.Stream(dev)
     hip = C.CDLL("libamdhip64.so")
