@@ -388,51 +388,85 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
     r.n = t / p.tiles_d;
     return r;
   };
+  // Per-thread constants of the staging roles (independent of the tile): halo cell (hd,hh,hw,part) of each of the
+  // NHL 16-byte loads, and the (row, column) of the 16 accumulator registers inside the wave's 4x8 voxel plane.
+  int hcd[NHL], hch[NHL], hcw[NHL];
+#pragma unroll
+  for (int k = 0; k < NHL; ++k) {
+    const int u = tid + k * 256;
+    const int vox = (u < I_NH * 2) ? (u >> 1) : 0;
+    hcw[k] = vox % I_HW;
+    const int t2 = vox / I_HW;
+    hch[k] = t2 % I_HH;
+    hcd[k] = (u < I_NH * 2) ? (t2 / I_HH) : (1 << 20);   // out-of-range depth marks the unused slots invalid
+  }
+  const int part16 = (tid & 1) * 16;
+
+  // All loads of a tile are UNCONDITIONAL on clamped coordinates (a load under a branch is waited for inside the
+  // branch and the two-tile prefetch collapses); validity travels as bit masks and is applied where the values
+  // are consumed (halo: at the LDS store; targets: at the loss accumulation).
   struct Regs {
     v4i h[NHL];
     float y[16];
+    unsigned hmask, ymask;
   };
   auto fetch = [&](int tile, Regs& R) {
     const Tile tl = decode(tile);
     const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
+    const size_t nbase = (size_t)tl.n * p.D;
+    unsigned hm = 0;
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
-      const int u = tid + k * 256;
-      const int vox = u >> 1, part = u & 1;
-      const int hw = vox % I_HW;
-      const int t2 = vox / I_HW;
-      const int hh = t2 % I_HH, hd = t2 / I_HH;
-      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-      R.h[k] = v4i{0, 0, 0, 0};
-      if (u < I_NH * 2 && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && p.debug != 2)
-        R.h[k] = *reinterpret_cast<const v4i*>(p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * 32 + part * 16);
+      const int id = id0 + hcd[k], ih = ih0 + hch[k], iw = iw0 + hcw[k];
+      const bool ok = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+      const int cd = min(max(id, 0), p.D - 1), chh = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
+      hm |= (ok ? 1u : 0u) << k;
+      R.h[k] = *reinterpret_cast<const v4i*>(p.x + (((nbase + cd) * p.H + chh) * p.W + cw) * 32 + part16);
     }
-    const int od = tl.od0 + wid;
+    R.hmask = (p.debug == 2) ? 0u : hm;
+    // targets: register r holds voxel (row r>>2, column (r&3) + 4*lh) of d-plane wid, channel ch0 + li
+    const int od = min(tl.od0 + wid, p.OD - 1);
+    const bool dok = tl.od0 + wid < p.OD;
+    const size_t ybase = (((size_t)tl.n * p.OD + od) * p.OH) * p.OW;
+    size_t rowoff[4];
+    int coloff[4];
+    unsigned rowok = 0, colok = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oh = tl.oh0 + q, ow = tl.ow0 + q + 4 * lh;
+      rowok |= (unsigned)(oh < p.OH) << q;
+      colok |= (unsigned)(ow < p.OW) << q;
+      rowoff[q] = (ybase + (size_t)min(oh, p.OH - 1) * p.OW) * p.C2 + ch0 + li;
+      coloff[q] = min(ow, p.OW - 1) * p.C2;
+    }
+    unsigned ym = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int oh = tl.oh0 + (i >> 3), ow = tl.ow0 + (i & 7);
-      R.y[r] = 0.0f;
-      if (od < p.OD && oh < p.OH && ow < p.OW && p.debug != 3)
-        R.y[r] = p.y[((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 + ch0 + li];
+      R.y[r] = p.y[rowoff[r >> 2] + coloff[r & 3]];
+      ym |= (((rowok >> (r >> 2)) & (colok >> (r & 3)) & 1u) & (dok ? 1u : 0u)) << r;
     }
+    R.ymask = (p.debug == 3) ? 0u : ym;
   };
 
   const int hv = (wid * I_HH + (li >> 3)) * I_HW + (li & 7);
   double l0 = 0.0;
   // one tile: store X's halo, refill X with tile+2, MFMAs, register epilogue against X's (saved) targets
-  auto body = [&](int tile, Regs& X) {
+  auto body = [&](int tile, Regs& X, bool more) {
     __syncthreads();                                       // previous tile's MFMAs are done with the halo
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
       const int u = tid + k * 256;
-      if (u < I_NH * 2) *reinterpret_cast<v4i*>(&halo[(u >> 1) * VS + (u & 1) * 16]) = X.h[k];
+      const v4i val = ((X.hmask >> k) & 1u) ? X.h[k] : v4i{0, 0, 0, 0};
+      if (u < I_NH * 2) *reinterpret_cast<v4i*>(&halo[(u >> 1) * VS + (u & 1) * 16]) = val;
     }
     float ycur[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ycur[r] = X.y[r];
+    const unsigned ymcur = X.ymask;
     __syncthreads();
-    if (tile + 2 < t_end) fetch(tile + 2, X);              // two tiles ahead, into the set just consumed
+    fetch(more ? tile + 2 : tile, X);                      // two tiles ahead, into the set just consumed (the last
+                                                           // two tiles harmlessly re-read themselves)
+    __builtin_amdgcn_sched_barrier(0);
     v16i acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0;
@@ -444,16 +478,10 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
       const v4i b = *reinterpret_cast<const v4i*>(&wl[((tap * 2 + lh) * 32 + li) * 16]);
       acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
     }
-    const Tile tl = decode(tile);
-    const int od = tl.od0 + wid;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int oh = tl.oh0 + (i >> 3), ow = tl.ow0 + (i & 7);
-      if (od < p.OD && oh < p.OH && ow < p.OW) {
-        const float d = ((float)acc[r] * scale + bv) - ycur[r];
-        l0 += (double)(d * d);
-      }
+      const float d = ((float)acc[r] * scale + bv) - ycur[r];
+      l0 += ((ymcur >> r) & 1u) ? (double)(d * d) : 0.0;
     }
   };
 
@@ -462,11 +490,12 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
   for (int k = 0; k < NHL; ++k) A.h[k] = B.h[k] = v4i{0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 16; ++r) A.y[r] = B.y[r] = 0.0f;
+  A.hmask = A.ymask = B.hmask = B.ymask = 0;
   if (t_begin < t_end) fetch(t_begin, A);
   if (t_begin + 1 < t_end) fetch(t_begin + 1, B);
   for (int tile = t_begin; tile < t_end; tile += 2) {
-    body(tile, A);
-    if (tile + 1 < t_end) body(tile + 1, B);
+    body(tile, A, tile + 2 < t_end);
+    if (tile + 1 < t_end) body(tile + 1, B, tile + 3 < t_end);
   }
   double v[2] = {l0, l0};
   grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
