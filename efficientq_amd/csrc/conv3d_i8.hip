@@ -250,66 +250,87 @@ __global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Para
     r.n = t / p.tiles_d;
     return r;
   };
-  auto load_halo = [&](const Tile& tl, v4i(&hreg)[NHL]) {
+  // per-thread staging constants (independent of the tile); all tile loads are unconditional on clamped
+  // coordinates with validity bits applied at the consumer (see k_conv3d_i8l)
+  int hcd[NHL], hch[NHL], hcw[NHL], hpart[NHL];
+#pragma unroll
+  for (int k = 0; k < NHL; ++k) {
+    const int u = tid + k * 256;
+    const bool live = u < I_NH * 2 * CG;
+    const int vox = live ? u / (2 * CG) : 0;
+    hpart[k] = live ? (u % (2 * CG)) * 16 : 0;
+    hcw[k] = vox % I_HW;
+    const int t2 = vox / I_HW;
+    hch[k] = t2 % I_HH;
+    hcd[k] = live ? (t2 / I_HH) : (1 << 20);
+  }
+  typedef float yv4 __attribute__((ext_vector_type(4)));
+  auto load_halo = [&](const Tile& tl, v4i(&hreg)[NHL], unsigned& hmask) {
     const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
+    const size_t nbase = (size_t)tl.n * p.D;
+    unsigned hm = 0;
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
-      const int u = tid + k * 256;
-      const int vox = u / (2 * CG), part = u % (2 * CG);
-      const int hw = vox % I_HW;
-      const int t2 = vox / I_HW;
-      const int hh = t2 % I_HH, hd = t2 / I_HH;
-      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-      hreg[k] = v4i{0, 0, 0, 0};                          // level id 0 == activation value 0 == zero padding
-      if (u < I_NH * 2 * CG && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-        hreg[k] = *reinterpret_cast<const v4i*>(p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 +
-                                                part * 16);
+      const int id = id0 + hcd[k], ih = ih0 + hch[k], iw = iw0 + hcw[k];
+      const bool ok = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+      const int cd = min(max(id, 0), p.D - 1), chh = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
+      hm |= (ok ? 1u : 0u) << k;
+      hreg[k] = *reinterpret_cast<const v4i*>(p.x + (((nbase + cd) * p.H + chh) * p.W + cw) * p.C1 + hpart[k]);
     }
+    hmask = hm;
   };
-  auto load_y = [&](const Tile& tl, float4(&yv)[4]) {
+  auto load_y = [&](const Tile& tl, yv4(&yv)[4], unsigned& ymask) {
+    unsigned ym = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int u = tid + k * 256;
       const int vox = u >> 3;
       const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
-      yv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (od < p.OD && oh < p.OH && ow < p.OW)
-        yv[k] = *reinterpret_cast<const float4*>(p.y + ((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 +
-                                                 ch0 + (u & 7) * 4);
+      ym |= (unsigned)(od < p.OD && oh < p.OH && ow < p.OW) << k;
+      const int cd = min(od, p.OD - 1), chh = min(oh, p.OH - 1), cw = min(ow, p.OW - 1);
+      yv[k] = *reinterpret_cast<const yv4*>(p.y + ((((size_t)tl.n * p.OD + cd) * p.OH + chh) * p.OW + cw) * p.C2 +
+                                            ch0 + (u & 7) * 4);
     }
+    ymask = ym;
   };
 
   const int hv = (wid * I_HH + (li >> 3)) * I_HW + (li & 7);
   double l0 = 0.0;
   v4i hreg[NHL];
-  float4 ynext[4], ycur[4];
+  yv4 ynext[4], ycur[4];
+  unsigned hmask = 0, ymask_next = 0, ymask_cur = 0;
+#pragma unroll
+  for (int k = 0; k < NHL; ++k) hreg[k] = v4i{0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ynext[k] = yv4{0.f, 0.f, 0.f, 0.f};
   if (t_begin < t_end) {
     const Tile t0 = decode(t_begin);
-    load_halo(t0, hreg);
-    load_y(t0, ynext);
+    load_halo(t0, hreg, hmask);
+    load_y(t0, ynext, ymask_next);
   }
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();                                       // halo free (previous tile's MFMAs done)
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
       const int u = tid + k * 256;
-      if (u < I_NH * 2 * CG) *reinterpret_cast<v4i*>(&halo[(u / (2 * CG)) * VS + (u % (2 * CG)) * 16]) = hreg[k];
+      const v4i val = ((hmask >> k) & 1u) ? hreg[k] : v4i{0, 0, 0, 0};   // level id 0 == zero padding
+      if (u < I_NH * 2 * CG) *reinterpret_cast<v4i*>(&halo[(u / (2 * CG)) * VS + (u % (2 * CG)) * 16]) = val;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) ycur[k] = ynext[k];
+    ymask_cur = ymask_next;
     __syncthreads();
-    if (tile + 1 < t_end) {
-      const Tile tn = decode(tile + 1);
-      load_halo(tn, hreg);
-      load_y(tn, ynext);
+    {
+      const Tile tn = decode((tile + 1 < t_end) ? tile + 1 : tile);   // the last tile harmlessly re-reads itself
+      load_halo(tn, hreg, hmask);
+      load_y(tn, ynext, ymask_next);
     }
+    __builtin_amdgcn_sched_barrier(0);
     v16i acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0;
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
-      constexpr int dummy = 0;
-      (void)dummy;
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
       const int8_t* arow = halo + (hv + (kd * I_HH + kh) * I_HW + kw) * VS + 16 * lh;
 #pragma unroll
@@ -325,17 +346,14 @@ __global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Para
       tb[(wid * 32 + i) * I_TS + li] = (float)acc[r] * scale + bv;
     }
     __syncthreads();
-    const Tile tl = decode(tile);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int u = tid + k * 256;
       const int vox = u >> 3, c4 = u & 7;
-      const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
-      if (od < p.OD && oh < p.OH && ow < p.OW) {
-        const float4 o = *reinterpret_cast<const float4*>(&tb[vox * I_TS + c4 * 4]);
-        const float d0 = o.x - ycur[k].x, d1 = o.y - ycur[k].y, d2 = o.z - ycur[k].z, d3 = o.w - ycur[k].w;
-        l0 += ((double)(d0 * d0) + (double)(d1 * d1)) + ((double)(d2 * d2) + (double)(d3 * d3));
-      }
+      const yv4 o = *reinterpret_cast<const yv4*>(&tb[vox * I_TS + c4 * 4]);
+      const float d0 = o[0] - ycur[k][0], d1 = o[1] - ycur[k][1], d2 = o[2] - ycur[k][2], d3 = o[3] - ycur[k][3];
+      const double q = ((double)(d0 * d0) + (double)(d1 * d1)) + ((double)(d2 * d2) + (double)(d3 * d3));
+      l0 += ((ymask_cur >> k) & 1u) ? q : 0.0;
     }
   }
   double v[2] = {l0, l0};

@@ -1,13 +1,13 @@
 """Launch one conv-step shape a few times (used under rocprofv3 --kernel-trace / --pmc so traces stay small).
 usage: prof_conv.py MODE [n]   MODE: f32_32 (32->32 3^3, 16x64^3, f32 MFMA) | i8_32 (same shape, exact-int)
-                               | f32_128 (128->128 3^3, 16x16^3)"""
+                               | f32_128 (128->128 3^3, 16x16^3) | i8_64 | i8_128 | i8_256 (exact-int, 16x32^3 / 16^3 / 8^3)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from efficientq_amd.hip_ops import get_ops, make_geom
 mode = sys.argv[1] if len(sys.argv) > 1 else "f32_32"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-N, C, S = (16, 128, 16) if mode == "f32_128" else (16, 32, 64)
+N, C, S = {"f32_128": (16, 128, 16), "i8_64": (16, 64, 32), "i8_128": (16, 128, 16), "i8_256": (16, 256, 8)}.get(mode, (16, 32, 64))
 dev = "cuda:0"
 ops = get_ops(dev)
 g = torch.Generator().manual_seed(0)
@@ -26,7 +26,7 @@ st_w = ops.new_fp_state()
 ops.weight_fixed_point(w, dual, v, 4, st_w)
 ops.admm_project_dual(v, w, st_w, 4, G, dual, 1.0, Gq)
 def step():
-    if mode == "i8_32":
+    if mode.startswith("i8"):
         ops.conv_step_i8(xidx, Gq, b, geom, y, alpha, 4, st_w, 4, sq)
     else:
         ops.conv_step(xq, G, b, geom, y, None, sqerr=sq)
@@ -38,6 +38,6 @@ for _ in range(n):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
 fl = 2.0 * C * C * 27 * N * S ** 3
-by = (4.0 * C + (1.0 if mode == "i8_32" else 4.0) * C) * N * S ** 3
+by = (4.0 * C + (1.0 if mode.startswith("i8") else 4.0) * C) * N * S ** 3
 print(f"{mode}: sqerr {sq.tolist()[0]:.6e}  avg {ms:.4f} ms  {fl / ms / 1e9:.2f} TFLOP/s ({fl / ms / 1e9 / 157.3 * 100:.1f}% f32 MFMA)  "
       f"{by / ms / 1e6:.0f} GB/s algorithmic ({by / ms / 1e6 / 8000 * 100:.1f}% of 8 TB/s)")
