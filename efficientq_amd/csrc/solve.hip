@@ -113,19 +113,53 @@ __device__ __forceinline__ void load_tile(double* dst, int ld, const double* src
   }
 }
 
-// mode 0 (row panel):   R[:, jb]   =  Dinv * A[kb, jb]                      grid.x = npad/64 (j blocks)
-// mode 1 (trailing):    A[ib, jb] -=  A[ib, kb] * R[:, jb]     (ib,jb != kb) grid = (npad/64, npad/64)
-// mode 2 (finalize):    A[ib, kb]  = -A[ib, kb] * Dinv (ib != kb);  A[kb, jb] = R[:, jb];  A[kb,kb] = Dinv
-template <int MODE>
-__global__ __launch_bounds__(256) void k_gj_step(double* __restrict__ A, int npad, int kb,
-                                                 const double* __restrict__ Dinv, double* __restrict__ R) {
+constexpr int GJ_CT = 4;     // column blocks per workgroup of the trailing update
+
+// ---- symmetric block Gauss-Jordan ---------------------------------------------------------------------
+// A is symmetric, and block Gauss-Jordan keeps a signed symmetry: with S = the pivot blocks already processed
+// and U the rest, M_ji = M_ij^T when i, j are both in S or both in U, and M_ji = -M_ij^T otherwise.  Only the
+// UPPER block triangle is therefore stored and updated: half the flops and - what matters, the rank-64 update
+// is HBM-bound - half the bytes per elimination step.  Per pivot block k:
+//   X_t = M_tk for every block row t != k   (t < k: block (t,k);  t > k: block (k,t)^T)
+//   Z_t = X_t * Dinv                        (Dinv = inv(M_kk), k_gj_diag)
+//   M_ij -= Z_i * (s_j X_j^T)  for i <= j, i, j != k,  s_j = -1 for j < k (j in S, k in U), +1 for j > k
+//   new M_tk = -Z_t (t < k),  new M_kt = Z_t^T (t > k),  new M_kk = Dinv.
+// k_gj_panel forms NZ = -Z (npad x 64, the A operand of the update) and XT = s * X^T (64 x npad, the B operand
+// in MFMA layout, coalesced) and writes the new pivot row/column; k_gj_trail_sym is the old trailing update on
+// the upper triangle with those operands.
+__global__ __launch_bounds__(256) void k_gj_panel(double* __restrict__ A, int npad, int kb,
+                                                  const double* __restrict__ Dinv, double* __restrict__ NZ,
+                                                  double* __restrict__ XT) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* As = sm;
-  double* Bs = sm + NBK * LDA_S;
+  double* As = sm;                  // X_t  [64][LDA_S]
+  double* Bs = sm + NBK * LDA_S;    // Dinv [64][LDB_S]
   const int kblk = kb / NBK;
-  const int jb = blockIdx.x, ib = blockIdx.y;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int t = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
+  if (t == kblk) {                  // A[kb,kb] = Dinv
+    for (int e = tid; e < NBK * NBK; e += 256) A[(size_t)(kb + (e >> 6)) * npad + kb + (e & 63)] = Dinv[e];
+    return;
+  }
+  const bool upper = t < kblk;      // X_t is the stored block (t,k); otherwise the transpose of block (k,t)
+  const double sgn = upper ? -1.0 : 1.0;
+  for (int e = tid; e < NBK * NBK; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    // stored element (r,c) of the source block; for the transposed case it is X[c][r]
+    const double v = upper ? A[(size_t)(t * NBK + r) * npad + kb + c] : A[(size_t)(kb + r) * npad + (size_t)t * NBK + c];
+    if (upper) {
+      As[r * LDA_S + c] = v;                                        // X[r][c]
+    } else {
+      As[c * LDA_S + r] = v;                                        // X[c][r] = block(k,t)[r][c]
+    }
+  }
+  load_tile(Bs, LDB_S, Dinv, NBK);
+  __syncthreads();
+  // XT[kk][t*64 + r] = s * X[r][kk]   (coalesced along r)
+  for (int e = tid; e < NBK * NBK; e += 256) {
+    const int kk = e >> 6, r = e & 63;
+    XT[(size_t)kk * npad + (size_t)t * NBK + r] = sgn * As[r * LDA_S + kk];
+  }
   f64x4 acc[2][2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -133,35 +167,7 @@ __global__ __launch_bounds__(256) void k_gj_step(double* __restrict__ A, int npa
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0;
-
-  if (MODE == 0) {
-    if (jb == kblk) return;
-    load_tile(As, LDA_S, Dinv, NBK);
-    load_tile(Bs, LDB_S, A + (size_t)kb * npad + (size_t)jb * NBK, npad);
-  } else if (MODE == 1) {
-    if (jb == kblk || ib == kblk) return;
-    load_tile(As, LDA_S, A + (size_t)ib * NBK * npad + kb, npad);
-    load_tile(Bs, LDB_S, R + (size_t)jb * NBK, npad);
-  } else {
-    // blockIdx.x enumerates both the column-panel tiles (ib = x) and the row-panel tiles
-    if (jb == kblk) {
-      // A[kb,kb] = Dinv
-      for (int e = threadIdx.x; e < NBK * NBK; e += 256)
-        A[(size_t)(kb + (e >> 6)) * npad + kb + (e & 63)] = Dinv[e];
-      return;
-    }
-    // row panel copy: A[kb, jb] = R[:, jb]
-    for (int e = threadIdx.x; e < NBK * NBK; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      A[(size_t)(kb + r) * npad + (size_t)jb * NBK + c] = R[(size_t)r * npad + (size_t)jb * NBK + c];
-    }
-    // column panel: tile ib = jb
-    load_tile(As, LDA_S, A + (size_t)jb * NBK * npad + kb, npad);
-    load_tile(Bs, LDB_S, Dinv, NBK);
-  }
-  __syncthreads();
-  tile_mma64(As, Bs, acc);
-
+  tile_mma64(As, Bs, acc);          // Z = X * Dinv
   const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -171,42 +177,35 @@ __global__ __launch_bounds__(256) void k_gj_step(double* __restrict__ A, int npa
       for (int r = 0; r < 4; ++r) {
         const int row = wr * 32 + mi * 16 + lk + 4 * r;
         const int col = wc * 32 + ni * 16 + lr;
-        if (MODE == 0) {
-          R[(size_t)row * npad + (size_t)jb * NBK + col] = acc[mi][ni][r];
-        } else if (MODE == 1) {
-          double* d = A + (size_t)(ib * NBK + row) * npad + (size_t)jb * NBK + col;
-          *d = *d - acc[mi][ni][r];
-        } else {
-          A[(size_t)(jb * NBK + row) * npad + kb + col] = -acc[mi][ni][r];
-        }
+        const double z = acc[mi][ni][r];
+        NZ[(size_t)(t * NBK + row) * NBK + col] = -z;
+        if (upper)
+          A[(size_t)(t * NBK + row) * npad + kb + col] = -z;          // new M_tk
+        else
+          A[(size_t)(kb + col) * npad + (size_t)t * NBK + row] = z;   // new M_kt = Z^T
       }
 }
 
-
-// Trailing update  A[ib, jb] -= A[ib, kb] * R[:, jb]  for a 64-row block ib and a strip of CT column
-// blocks.  The (negated) A[ib,kb] tile is staged once in LDS; the accumulators are INITIALISED with the
-// C tile (row = lk+4r, col = lr: 128-byte row segments), the R operand streams from L2 in MFMA B layout
-// (16 consecutive doubles per k row), and the result is stored back: one read + one write of the matrix
-// per elimination step, no separate read-modify-write pass.
-constexpr int GJ_CT = 4;
-__global__ __launch_bounds__(256) void k_gj_trail(double* __restrict__ A, int npad, int kb, const double* __restrict__ R) {
+__global__ __launch_bounds__(256) void k_gj_trail_sym(double* __restrict__ A, int npad, int kb,
+                                                      const double* __restrict__ NZ, const double* __restrict__ XT) {
   __shared__ __attribute__((aligned(16))) double As[NBK * LDA_S];
   const int kblk = kb / NBK, nblk = npad / NBK;
   const int ib = blockIdx.y;
   if (ib == kblk) return;
+  if ((int)(blockIdx.x * GJ_CT + GJ_CT - 1) < ib) return;        // the whole strip lies below the diagonal
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int lr = lane & 15, lk = lane >> 4;
   for (int e = tid; e < NBK * NBK; e += 256) {
     const int r = e >> 6, c = e & 63;
-    As[r * LDA_S + c] = -A[(size_t)(ib * NBK + r) * npad + kb + c];
+    As[r * LDA_S + c] = NZ[(size_t)(ib * NBK + r) * NBK + c];      // -Z_i
   }
   __syncthreads();
   for (int t = 0; t < GJ_CT; ++t) {
     const int jb = blockIdx.x * GJ_CT + t;
-    if (jb >= nblk || jb == kblk) continue;
+    if (jb >= nblk || jb == kblk || jb < ib) continue;
     double* Cb = A + (size_t)(ib * NBK + wr * 32) * npad + (size_t)jb * NBK + wc * 32;
-    const double* Rb = R + (size_t)jb * NBK + wc * 32;
+    const double* Rb = XT + (size_t)jb * NBK + wc * 32;
     f64x4 acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -241,8 +240,9 @@ __global__ __launch_bounds__(256) void k_a64_to_f32(const double* __restrict__ A
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += stride) {
     const int i = (int)(e / lda), j = (int)(e % lda);
-    // symmetrise: the exact inverse is symmetric; average the two computed halves.  Columns >= n are padding.
-    Ainv[e] = (j < n) ? (float)(0.5 * (A64[(size_t)i * npad + j] + A64[(size_t)j * npad + i])) : 0.0f;
+    // only the upper block triangle is maintained (symmetric Gauss-Jordan): mirror it.  Columns >= n are padding.
+    const int a = (i < j) ? i : j, b = (i < j) ? j : i;
+    Ainv[e] = (j < n) ? (float)A64[(size_t)a * npad + b] : 0.0f;
   }
 }
 
@@ -448,7 +448,7 @@ extern "C" {
 size_t effq_spd_inverse_ws_bytes(int n) {
   if (n <= 0) return 0;
   const size_t npad = (size_t)round_up(n, NBK);
-  return npad * npad * sizeof(double) + (size_t)NBK * npad * sizeof(double) + NBK * NBK * sizeof(double) + 256;
+  return npad * npad * sizeof(double) + 2 * (size_t)NBK * npad * sizeof(double) + NBK * NBK * sizeof(double) + 256;
 }
 
 int effq_ainv_ld(int n) { return n > 0 ? round_up(n, 32) : 0; }
@@ -464,8 +464,9 @@ int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double et
   const int npad = round_up(n, NBK);
   const int nblk = npad / NBK;
   double* A64 = reinterpret_cast<double*>(ws);
-  double* R = A64 + (size_t)npad * npad;
-  double* Dinv = R + (size_t)NBK * npad;
+  double* XT = A64 + (size_t)npad * npad;        // [64][npad]
+  double* NZ = XT + (size_t)NBK * npad;          // [npad][64]
+  double* Dinv = NZ + (size_t)NBK * npad;
   hipStream_t st = as_stream(stream);
   {
     size_t nb = ((size_t)npad * npad + 255) / 256;
@@ -476,19 +477,15 @@ int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double et
   const size_t lds = (size_t)(NBK * LDA_S + NBK * LDB_S) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_step<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_step<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   for (int k = 0; k < nblk; ++k) {
     const int kb = k * NBK;
     hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(256), 0, st, A64, npad, kb, Dinv);
-    if (nblk > 1) {
-      hipLaunchKernelGGL(k_gj_step<0>, dim3(nblk, 1), dim3(256), lds, st, A64, npad, kb, Dinv, R);
-      hipLaunchKernelGGL(k_gj_trail, dim3((nblk + GJ_CT - 1) / GJ_CT, nblk), dim3(256), 0, st, A64, npad, kb, R);
-    }
-    hipLaunchKernelGGL(k_gj_step<2>, dim3(nblk, 1), dim3(256), lds, st, A64, npad, kb, Dinv, R);
+    hipLaunchKernelGGL(k_gj_panel, dim3(nblk), dim3(256), lds, st, A64, npad, kb, Dinv, NZ, XT);
+    if (nblk > 1)
+      hipLaunchKernelGGL(k_gj_trail_sym, dim3((nblk + GJ_CT - 1) / GJ_CT, nblk), dim3(256), 0, st, A64, npad, kb, NZ, XT);
     EFFQ_LAUNCH_CHECK();
   }
   {
