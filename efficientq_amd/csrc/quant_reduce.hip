@@ -225,73 +225,92 @@ __global__ __launch_bounds__(TPB) void k_fp_iter(const float* __restrict__ x, si
 // 1024-thread workgroup computes mean|v|, then iterates statistics + update until convergence or the
 // cap, all on chip.  v = a + b2 (b2 may be NULL) is formed on the fly and optionally stored to v_out.
 constexpr int FPS_T = 1024;
-constexpr int FPS_PER = 32;     // elements per thread held in registers: n <= 32768
-__global__ __launch_bounds__(FPS_T) void k_fp_small(const float* __restrict__ a, const float* __restrict__ b2,
-                                                    float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
-                                                    double hi, double d, double tol, int max_iter) {
-  __shared__ double smem[2 * 16];
-  __shared__ double s_alpha;
-  __shared__ int s_done;
-  const int tid = threadIdx.x;
-  const int kmax = (int)((n + FPS_T - 1) / FPS_T);   // live register slots (uniform)
-  float vr[FPS_PER];
-  double acc[2] = {0.0, 0.0};
+// One barrier per iteration: every wave publishes its two partial sums into a parity-double-buffered LDS table,
+// and EVERY thread adds the table in wave order and takes the division itself (same bits everywhere), so there is
+// no serial thread-0 section and no broadcast barrier.  At 256 levels the weight fixed point of the first conv
+// runs ~300 iterations per ADMM iteration: the per-iteration latency (2.2 us with three barriers) is what counts.
+// PER = register slots per thread (compile time, so the element loop is branch-free and the fp64 chains of the
+// slots interleave).
+template <int T, int PER>
+__global__ __launch_bounds__(T) void k_fp_small(const float* __restrict__ a, const float* __restrict__ b2,
+                                                float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
+                                                double hi, double d, double tol, int max_iter) {
+  constexpr int NW = T / 64;
+  __shared__ double part[2][2][NW];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int kmax = (int)((n + T - 1) / T);   // live register slots (uniform)
+  float vr[PER];
+  unsigned live = 0;
+  double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-  for (int k = 0; k < FPS_PER; ++k) {
-    const size_t i = (size_t)tid + (size_t)k * FPS_T;
+  for (int k = 0; k < PER; ++k) {
+    const size_t i = (size_t)tid + (size_t)k * T;
     float v = 0.0f;
-    if (k < kmax && i < n) {
+    if (i < n) {
       v = (b2 != nullptr) ? (a[i] + b2[i]) : a[i];
       if (v_out != nullptr) v_out[i] = v;
+      live |= 1u << k;
     }
     vr[k] = v;
-    acc[0] += fabs((double)v);
+    acc0 += fabs((double)v);
   }
-  block_sum<2>(acc, smem);
-  if (tid == 0) {
-    s_alpha = acc[0] / (double)n;
-    s_done = 0;
-  }
+  acc0 = wave_sum(acc0);
+  if (lane == 0) part[0][0][wid] = acc0;
   __syncthreads();
-  double alpha = s_alpha, alpha_prev = -999.0;
-  int it = 0, done = 0;
-  while (!done) {
-    acc[0] = acc[1] = 0.0;
-    const double ralpha = 1.0 / alpha, rd = 1.0 / d;
+  double tot = 0.0;
 #pragma unroll
-    for (int k = 0; k < FPS_PER; ++k) {
-      const size_t i = (size_t)tid + (size_t)k * FPS_T;
-      if (k < kmax && i < n) {
+  for (int w = 0; w < NW; ++w) tot += part[0][0][w];
+  double alpha = tot / (double)n, alpha_prev = -999.0;
+  double ralpha = (double)n / tot;           // disc64_fast only needs a reciprocal good to a few ulp
+  double last0 = 0.0, last1 = 0.0;
+  int it = 0, done = 0;
+  const double rd = 1.0 / d;
+  while (!done) {
+    const int par = (it + 1) & 1;            // parity 0 carried the abs-sum
+    acc0 = acc1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      // 1024 threads leave 128 VGPRs: interleaving the fp64 chains of all slots spills there, so that variant
+      // keeps a (uniform) branch per slot, which serialises them; the 256-thread variants run branch-free
+      if (T < 1024 || k < kmax) {
         const double v = (double)vr[k];
         double r;
         const double bq = disc64_fast(v, alpha, ralpha, lo, hi, d, rd, &r);
-        acc[0] += bq * v;
-        acc[1] += bq * bq;
+        acc0 += bq * v;                        // dead slots hold v = 0
+        acc1 += ((live >> k) & 1u) ? bq * bq : 0.0;
       }
     }
-    block_sum<2>(acc, smem);
-    if (tid == 0) {
-      const double a_new = acc[0] / acc[1];
-      int dn = 0;
-      if (it + 1 >= max_iter)
-        dn = 2;
-      else if (!(fabs(a_new - alpha) > tol))
-        dn = 1;
-      s_alpha = a_new;
-      s_done = dn;
-      st->sums[0] = acc[0];
-      st->sums[1] = acc[1];
+    acc0 = wave_sum(acc0);
+    acc1 = wave_sum(acc1);
+    if (lane == 0) {
+      part[par][0][wid] = acc0;
+      part[par][1][wid] = acc1;
     }
     __syncthreads();
-    alpha_prev = alpha;
-    alpha = s_alpha;
-    done = s_done;
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      t0 += part[par][0][w];
+      t1 += part[par][1][w];
+    }
+    const double a_new = t0 / t1;
+    const double ra_new = t1 / t0;           // independent of the division above (pipelines with it)
     ++it;
-    __syncthreads();
+    if (it >= max_iter)
+      done = 2;
+    else if (!(fabs(a_new - alpha) > tol))
+      done = 1;
+    alpha_prev = alpha;
+    alpha = a_new;
+    ralpha = ra_new;
+    last0 = t0;
+    last1 = t1;
   }
   if (tid == 0) {
     st->alpha = alpha;
     st->alpha_prev = alpha_prev;
+    st->sums[0] = last0;
+    st->sums[1] = last1;
     st->iters = it;
     st->done = done;
   }
@@ -637,8 +656,29 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
   EFFQ_CHECK_ARG(n <= effq_fp_small_max());
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
   const double d = (hi - lo) / (double)(levels - 1);
-  hipLaunchKernelGGL(k_fp_small, dim3(1), dim3(FPS_T), 0, as_stream(stream), a, b, v_out, n, state_dev, lo, hi, d, tol,
-                     max_iter);
+  {
+    // threads: 256 up to 8192 elements (4 waves: the barrier is cheap and at <= 32 slots the element loop is short),
+    // else 1024; slots per thread rounded up to a power of 2
+    const int T = (n <= (size_t)256 * 32) ? 256 : FPS_T;
+    int per = (int)((n + T - 1) / T), pp = 1;
+    while (pp < per) pp <<= 1;
+    hipStream_t st = as_stream(stream);
+#define EFFQ_FPS(TT, PP)                                                                                          \
+  hipLaunchKernelGGL((k_fp_small<TT, PP>), dim3(1), dim3(TT), 0, st, a, b, v_out, n, state_dev, lo, hi, d, tol, max_iter)
+    if (T == 256) {
+      switch (pp) {
+        case 1: EFFQ_FPS(256, 1); break;
+        case 2: EFFQ_FPS(256, 2); break;
+        case 4: EFFQ_FPS(256, 4); break;
+        case 8: EFFQ_FPS(256, 8); break;
+        case 16: EFFQ_FPS(256, 16); break;
+        default: EFFQ_FPS(256, 32); break;
+      }
+    } else {
+      if (pp <= 16) EFFQ_FPS(1024, 16); else EFFQ_FPS(1024, 32);
+    }
+#undef EFFQ_FPS
+  }
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }
