@@ -71,11 +71,26 @@ class HipOps:
         self._red_ws = torch.zeros(self.lib.effq_reduce_ws_bytes(), dtype=torch.uint8, device=device)
         self._ws = {}
         self._att_cache = {}
+        self._pinned_stream = None
 
     # -- plumbing ---------------------------------------------------------------------------
     @property
     def stream(self):
+        # looking the current stream up through torch costs ~4 us per op; a caller that issues hundreds of ops on
+        # a known stream pins it with on_stream()
+        if self._pinned_stream is not None:
+            return self._pinned_stream
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def on_stream(self, stream: Optional["torch.cuda.Stream"]):
+        """Pin the HIP stream the following ops launch on (None: follow torch's current stream again).
+        Returns the previous pin so that callers can restore it."""
+        prev = self._pinned_stream
+        self._pinned_stream = None if stream is None else C.c_void_p(stream.cuda_stream)
+        return prev
+
+    def restore_stream(self, pin):
+        self._pinned_stream = pin
 
     def loss_stream(self):
         """The stream the per-iteration loss evaluation runs on, one iteration behind the ADMM chain."""

@@ -287,6 +287,16 @@ class EfficientQConvHIP(PTQConv):
         loss_s = getattr(ops, "loss_stream", lambda: None)() if self.lwq_overlap_loss else None
         main_s = torch.cuda.current_stream(dev) if loss_s is not None else None
         ev_loss = [None, None]
+        # events are reused per iteration parity (a wait captures the record that precedes it), and the library ops
+        # are pinned to their stream instead of looking torch's current stream up on every call
+        ev_main = [torch.cuda.Event(), torch.cuda.Event()] if loss_s is not None else None
+        ev_done = [torch.cuda.Event(), torch.cuda.Event()] if loss_s is not None else None
+        pin = getattr(ops, "on_stream", None)
+        if pin is not None:
+            ops.restore_stream(None)     # (a pin left behind by an earlier exception)
+        # torch-side work inside the loss step follows torch's CURRENT stream: the collectives of the data-parallel
+        # reducer and the .item() of the trace need the stream context, the plain library ops only the pin
+        needs_ctx = bool(red) or bool(self.lwq_trace)
         # A = A0 + rho*I' + eta*I changes only with rho, and the rho schedule is known up front (5 values per
         # layer): the first inverse is formed on the calibration stream, the later ones on a side stream under
         # the ADMM iterations that precede their first use (EfficientQConv.py:129-137 fixes when that is).
@@ -310,6 +320,7 @@ class EfficientQConvHIP(PTQConv):
                     ev = torch.cuda.Event()
                     ev.record(side)
                     inv_of[r_] = (buf, ev)
+        main_pin = pin(main_s) if (pin is not None and main_s is not None) else None
         Ainv, rho_of_inv = None, None
         import time as _time
         t_loop0 = _time.perf_counter()
@@ -363,16 +374,23 @@ class EfficientQConvHIP(PTQConv):
             if loss_s is None:
                 loss_step()
             else:
-                ev = torch.cuda.Event()
-                ev.record(main_s)
-                with torch.cuda.stream(loss_s):
-                    loss_s.wait_event(ev)
+                ev_main[p_].record(main_s)
+                loss_s.wait_event(ev_main[p_])
+                prev_pin = pin(loss_s) if pin is not None else None
+                if needs_ctx or pin is None:
+                    with torch.cuda.stream(loss_s):
+                        loss_step()
+                else:
                     loss_step()
-                    ev_loss[p_] = torch.cuda.Event()
-                    ev_loss[p_].record(loss_s)
+                if pin is not None:
+                    ops.restore_stream(prev_pin)
+                ev_done[p_].record(loss_s)
+                ev_loss[p_] = ev_done[p_]
             if i % RHO_PERIOD == 0:
                 rho = rho * 2 if rho * 2 <= rho_m else rho_m
 
+        if pin is not None and main_s is not None:
+            ops.restore_stream(main_pin)
         t_enq = _time.perf_counter() - t_loop0     # host time to enqueue the 200 iterations (diagnostic)
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
