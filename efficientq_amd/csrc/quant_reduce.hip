@@ -3,6 +3,7 @@
 // All arithmetic follows the reference's operation order with IEEE divisions and no FMA
 // contraction (the library is built with -ffp-contract=off).
 #include <stdarg.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace effq {
@@ -657,9 +658,13 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
   const double d = (hi - lo) / (double)(levels - 1);
   {
-    // threads: 256 up to 8192 elements (4 waves: the barrier is cheap and at <= 32 slots the element loop is short),
-    // else 1024; slots per thread rounded up to a power of 2
-    const int T = (n <= (size_t)256 * 32) ? 256 : FPS_T;
+    // threads: 256 up to 2048 elements, 512 up to 16384 (few waves: the barrier is cheap and the element loop stays
+    // short; measured best on MI355X, scripts/exp_fp256.py), else 1024; slots per thread rounded up to a power of 2.  EFFQ_FPS_T overrides (tuning aid).
+    static const int force_t = getenv("EFFQ_FPS_T") ? atoi(getenv("EFFQ_FPS_T")) : 0;
+    int T = (n <= 2048) ? 256 : (n <= 16384) ? 512 : FPS_T;
+    if (force_t == 256 && n <= 8192) T = 256;
+    if (force_t == 512 && n <= 16384) T = 512;
+    if (force_t == 1024) T = 1024;
     int per = (int)((n + T - 1) / T), pp = 1;
     while (pp < per) pp <<= 1;
     hipStream_t st = as_stream(stream);
@@ -673,6 +678,13 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
         case 8: EFFQ_FPS(256, 8); break;
         case 16: EFFQ_FPS(256, 16); break;
         default: EFFQ_FPS(256, 32); break;
+      }
+    } else if (T == 512) {
+      switch (pp) {
+        case 1: case 2: case 4: EFFQ_FPS(512, 4); break;
+        case 8: EFFQ_FPS(512, 8); break;
+        case 16: EFFQ_FPS(512, 16); break;
+        default: EFFQ_FPS(512, 32); break;
       }
     } else {
       if (pp <= 16) EFFQ_FPS(1024, 16); else EFFQ_FPS(1024, 32);
