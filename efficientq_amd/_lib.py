@@ -71,6 +71,9 @@ SIGNATURES = {
     "effq_gram_i8_supported": (_I, [_GP, _I]),
     "effq_gram_i8_ws_bytes": (_SZ, [_GP, _I]),
     "effq_gram_accum_i8": (_I, [_P, _P, _GP, _I, _P, _I, _P, _P, _P, _I, _LL, _P, _P, _I, _P, _SZ, _P]),
+    "effq_packed_bytes": (_SZ, [_SZ, _I]),
+    "effq_pack_levels": (_I, [_P, _SZ, _I, _P, _P]),
+    "effq_unpack_levels": (_I, [_P, _SZ, _I, _P, _P]),
     "effq_ainv_ld": (_I, [_I]),
     "effq_spd_inverse_ws_bytes": (_SZ, [_I]),
     "effq_spd_inverse": (_I, [_P, _I, _I, _D, _D, _P, _P, _SZ, _P]),

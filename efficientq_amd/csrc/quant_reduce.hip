@@ -550,6 +550,30 @@ __global__ __launch_bounds__(TPB) void k_adam(float* __restrict__ p, const float
   }
 }
 
+// ---- bit-packed storage of level ids (row f2: the reference stores one uint8 per weight, PTQConv.py:125-152) ----
+// element i occupies bits [i*bits, (i+1)*bits) of the little-endian bit stream; bits in {1, 2, 4, 8}
+__global__ __launch_bounds__(TPB) void k_pack_levels(const uint8_t* __restrict__ idx, size_t n, int bits,
+                                                     uint8_t* __restrict__ packed, size_t nbytes) {
+  const int per = 8 / bits;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < nbytes; b += stride) {
+    unsigned v = 0;
+    for (int k = 0; k < per; ++k) {
+      const size_t i = b * per + k;
+      if (i < n) v |= ((unsigned)idx[i] & ((1u << bits) - 1u)) << (k * bits);
+    }
+    packed[b] = (uint8_t)v;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_unpack_levels(const uint8_t* __restrict__ packed, size_t n, int bits,
+                                                       uint8_t* __restrict__ idx) {
+  const int per = 8 / bits;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    idx[i] = (uint8_t)((packed[i / per] >> ((i % per) * bits)) & ((1u << bits) - 1u));
+}
+
 }  // namespace effq
 
 using namespace effq;
@@ -770,6 +794,31 @@ int effq_adam_step(float* p, const float* g, float* m, float* v, float lr, float
   const float bc1 = 1.0f - powf(b1, (float)t), bc2 = 1.0f - powf(b2, (float)t);
   hipLaunchKernelGGL(k_adam, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), p, g, m, v, lr, b1, b2, eps, bc1,
                      bc2, n);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+size_t effq_packed_bytes(size_t n, int bits) {
+  if (!(bits == 1 || bits == 2 || bits == 4 || bits == 8)) return 0;
+  return (n * (size_t)bits + 7) / 8;
+}
+
+int effq_pack_levels(const uint8_t* idx, size_t n, int bits, uint8_t* packed, void* stream) {
+  EFFQ_CHECK_ARG(bits == 1 || bits == 2 || bits == 4 || bits == 8);
+  if (n == 0) return EFFQ_OK;
+  EFFQ_CHECK_ARG(idx && packed);
+  const size_t nbytes = effq_packed_bytes(n, bits);
+  hipLaunchKernelGGL(k_pack_levels, dim3(stream_grid(nbytes)), dim3(TPB), 0, as_stream(stream), idx, n, bits, packed,
+                     nbytes);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_unpack_levels(const uint8_t* packed, size_t n, int bits, uint8_t* idx, void* stream) {
+  EFFQ_CHECK_ARG(bits == 1 || bits == 2 || bits == 4 || bits == 8);
+  if (n == 0) return EFFQ_OK;
+  EFFQ_CHECK_ARG(idx && packed);
+  hipLaunchKernelGGL(k_unpack_levels, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), packed, n, bits, idx);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

@@ -315,6 +315,33 @@ class HipOps:
                                           ws.numel(), self.stream), "effq_gram_accum_i8")
         return A0, B0
 
+    # -- f2: bit-packed level ids -------------------------------------------------------------
+    @staticmethod
+    def storage_bits(levels: int) -> int:
+        """Smallest supported field width (1/2/4/8 bits) that holds `levels` level ids."""
+        for b in (1, 2, 4, 8):
+            if levels <= (1 << b):
+                return b
+        raise _lib.EffqError(f"{levels} levels do not fit 8 bits")
+
+    def pack_levels(self, idx: torch.Tensor, bits: int) -> torch.Tensor:
+        if idx.dtype != torch.uint8 or not idx.is_contiguous():
+            raise _lib.EffqError("pack_levels wants contiguous uint8 level ids")
+        nb = self.lib.effq_packed_bytes(idx.numel(), int(bits))
+        if idx.numel() and nb == 0:
+            raise _lib.EffqError(f"unsupported field width {bits}")
+        out = torch.empty(int(nb), dtype=torch.uint8, device=idx.device)
+        check(self.lib.effq_pack_levels(_ptr(idx), idx.numel(), int(bits), _ptr(out), self.stream), "effq_pack_levels")
+        return out
+
+    def unpack_levels(self, packed: torch.Tensor, n: int, bits: int) -> torch.Tensor:
+        if packed.dtype != torch.uint8 or packed.numel() != self.lib.effq_packed_bytes(int(n), int(bits)):
+            raise _lib.EffqError("unpack_levels: buffer does not match n and the field width")
+        out = torch.empty(int(n), dtype=torch.uint8, device=packed.device)
+        check(self.lib.effq_unpack_levels(_ptr(packed.contiguous()), int(n), int(bits), _ptr(out), self.stream),
+              "effq_unpack_levels")
+        return out
+
     # -- a7 -----------------------------------------------------------------------------------
     def spd_inverse(self, A0: torch.Tensor, has_bias: bool, rho: float, eta: float,
                     out: Optional[torch.Tensor] = None, ws_key: str = "inv") -> torch.Tensor:

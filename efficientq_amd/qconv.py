@@ -160,6 +160,25 @@ class PTQConv(nn.Conv3d):
         b = self.weight.data.float() * delta - 1
         self.weight.data = self.alpha_w.data * b
 
+    # ---- bit-packed storage (row f2; the reference keeps one uint8 per weight) ------------------
+    def export_packed_weight(self):
+        """Level ids of the quantised weight packed at 1/2/4/8 bits each: dict(data, n, bits, shape, alpha_w, levels).
+        Same level ids as store_int_weight(); the module is left untouched."""
+        ops = get_ops(self.weight.device)
+        delta = 2 / (self.qlvl_w - 1)
+        ids = torch.round((self.weight.data / self.alpha_w.data + 1) / delta).to(torch.uint8).contiguous().reshape(-1)
+        bits = ops.storage_bits(self.qlvl_w)
+        return dict(data=ops.pack_levels(ids, bits).cpu(), n=int(ids.numel()), bits=bits,
+                    shape=tuple(self.weight.shape), alpha_w=float(self.alpha_w.data), levels=int(self.qlvl_w))
+
+    def import_packed_weight(self, blob):
+        """Inverse of export_packed_weight(): weight = alpha_w * (2*id/(L-1) - 1), like restore_fp_weight()."""
+        ops = get_ops(self.weight.device)
+        ids = ops.unpack_levels(blob["data"].to(self.weight.device), blob["n"], blob["bits"])
+        delta = 2 / (blob["levels"] - 1)
+        self.alpha_w.data = torch.tensor(blob["alpha_w"], dtype=self.weight.dtype, device=self.weight.device)
+        self.weight.data = (self.alpha_w.data * (ids.float() * delta - 1)).reshape(blob["shape"])
+
     # ---- forward dispatch (PTQConv.py:154-174) ----------------------------------------------
     def forward(self, x):
         if self._fp:

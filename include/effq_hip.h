@@ -228,6 +228,13 @@ int conv3d_calib_step_i8s(const uint8_t* xidx_ndhwc, const int8_t* Gq, const flo
 int effq_adam_step(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
                    int t, size_t n, void* stream);
 
+/* ---- f2: bit-packed storage of level ids ---------------------------------------------------
+ * The reference stores one uint8 per weight (store_int_weight, PTQConv.py:125-152); these pack the level ids
+ * at 1/2/4/8 bits each (little-endian bit stream: element i in bits [i*bits, (i+1)*bits)) and back. */
+size_t effq_packed_bytes(size_t n, int bits);
+int effq_pack_levels(const uint8_t* idx, size_t n, int bits, uint8_t* packed, void* stream);
+int effq_unpack_levels(const uint8_t* packed, size_t n, int bits, uint8_t* idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -506,3 +506,19 @@ def test_cooperative_weight_fixed_point_matches_oracle(ops, n, L):
     st2 = ops.new_fp_state()
     ops.weight_fixed_point(dev(w), dev(du), v, L, st2)
     assert ops.read_fp_state(st2) == (alpha, iters, done)
+
+
+@pytest.mark.parametrize("bits,levels,n", [(2, 4, 27648), (4, 16, 1001), (1, 2, 77), (8, 256, 513), (2, 3, 5), (4, 16, 0)])
+def test_bit_packed_level_storage_round_trip(ops, bits, levels, n):
+    """Row f2: level ids packed at 1/2/4/8 bits (the reference keeps one uint8 per weight, PTQConv.py:125-152)."""
+    gen = torch.Generator().manual_seed(bits * 1000 + n)
+    idx = torch.randint(0, levels, (n,), generator=gen).to(torch.uint8)
+    assert ops.storage_bits(levels) == bits
+    packed = ops.pack_levels(dev(idx), bits)
+    assert packed.numel() == (n * bits + 7) // 8
+    # little-endian bit stream, checked against numpy
+    want = np.zeros(packed.numel(), dtype=np.uint8)
+    for i, v in enumerate(idx.numpy()):
+        want[(i * bits) // 8] |= np.uint8((int(v) << ((i * bits) % 8)) & 0xFF)
+    assert np.array_equal(packed.cpu().numpy(), want)
+    assert torch.equal(ops.unpack_levels(packed, n, bits).cpu(), idx)
