@@ -7,7 +7,7 @@ Run only in the build container (``/root/reference`` present):
 The reference is imported read-only (``sys.dont_write_bytecode``); its one
 missing dependency on the orchestrator path, ``nibabel``, is replaced by a
 no-op stand-in module.  Only inputs and outputs (data)
-are written; no reference source travels.  Fixtures: G1..G10 of SURVEY.md 8(c).
+are written; no reference source travels.  Fixtures: G1..G10 of SURVEY.md 8(c), G11 for row f1.
 """
 import argparse
 import os
@@ -440,8 +440,37 @@ def g10():
     save("g10_resblock_mid.npz", **rec)
 
 
+def g11():
+    """Row f1: sliding-window split / stitch (utils/transforms.py:784-852) and the FP-vs-Q Dice helper
+    (utils/metrics.py:21-25, 119-148)."""
+    from utils import transforms as tfm
+    from utils import metrics as M
+    gen = torch.Generator().manual_seed(11)
+    out = {}
+    for tag, shape, psz, ov in (("a", (2, 2, 12, 13, 14), 6, 2), ("b", (1, 1, 12, 12, 12), (6, 12, 6), (2, 0, 3)),
+                                ("c", (1, 1, 7, 8, 9), 7, 3)):
+        img = torch.randn(*shape, generator=gen)
+        patches = tfm.image_to_patch3d(img, psz, ov)
+        out[f"{tag}_img"] = img
+        out[f"{tag}_npatch"] = np.int64(len(patches))
+        out[f"{tag}_patches"] = torch.stack(patches)
+        # "network output": 2 heads x (a function of the patch), stitched like validate_seg does (validate.py:240-245)
+        preds = [torch.stack([p * 2.0 + 1.0, p.flip(1) - 0.5]) for p in patches]
+        out[f"{tag}_stitched"] = tfm.patch_to_image3d(img, preds, psz, ov)
+    logits = torch.randn(2, 3, 6, 7, 8, generator=gen)
+    tgt_l = torch.randint(0, 3, (2, 6, 7, 8), generator=gen)
+    tgt_b = torch.randint(0, 2, (2, 3, 6, 7, 8), generator=gen)
+    out["m_logits"], out["m_tgt_lits"], out["m_tgt_brats"] = logits, tgt_l, tgt_b
+    out["m_dice_lits"] = torch.stack([d.float() for d in M.validate_vs_label(logits, tgt_l, "lits")])
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):        # the brats branch prints the shape
+        out["m_dice_brats"] = torch.stack([d.float() for d in M.validate_vs_label(logits, tgt_b, "brats")])
+    out["m_dice_empty"] = M.dice(torch.zeros(4, dtype=torch.bool), torch.zeros(4, dtype=torch.bool)).float()
+    save("g11_sliding_window.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3g4", "g5", "g6", "g6b", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3g4", "g5", "g6", "g6b", "g7", "g8", "g9", "g10", "g11"]
     with torch.no_grad():
         if "g1" in which:
             g1()
@@ -457,6 +486,8 @@ if __name__ == "__main__":
             g9()
         if "g10" in which:
             g10()
+        if "g11" in which:
+            g11()
     if "g5" in which:
         g5()
     if "g6" in which:

@@ -255,3 +255,24 @@ def test_data_parallel_two_ranks_gloo_matches_single_rank(tmp_path):
     assert dp0["nums"] == single["nums"]
     a, b = np.array(dp0["loss"]), np.array(single["loss"])
     assert np.all(np.abs(a - b) <= 1e-3 * b), (a, b)
+
+
+@pytest.mark.parametrize("tag,psz,ov", [("a", 6, 2), ("b", (6, 12, 6), (2, 0, 3)), ("c", 7, 3)])
+def test_sliding_window_helpers_match_reference(gold, tag, psz, ov):
+    """Row f1 host logic (efficientq_amd/evaluate.py) against the reference's split / stitch / Dice goldens."""
+    from efficientq_amd import evaluate as E
+    g = gold("g11_sliding_window.npz")
+    img = torch.from_numpy(g[f"{tag}_img"])
+    patches = E.image_to_patch3d(img, psz, ov)
+    assert torch.equal(torch.stack(patches), torch.from_numpy(g[f"{tag}_patches"]))
+    preds = [torch.stack([p * 2.0 + 1.0, p.flip(1) - 0.5]) for p in patches]
+    assert torch.equal(E.patch_to_image3d(img, preds, psz, ov), torch.from_numpy(g[f"{tag}_stitched"]))
+    # the driver loop over a "model": identity heads give the image back wherever patches agree
+    out = E.sliding_window_forward(lambda p: [p, 2 * p], img, psz, ov)
+    assert out.shape == (2,) + tuple(img.shape) and torch.allclose(out[0], img, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        E.image_to_patch3d(img, 64, 2)                      # patch larger than the image
+    logits = torch.from_numpy(g["m_logits"])
+    d_l = torch.stack([d.float() for d in E.validate_vs_label(logits, torch.from_numpy(g["m_tgt_lits"]), "lits")])
+    d_b = torch.stack([d.float() for d in E.validate_vs_label(logits, torch.from_numpy(g["m_tgt_brats"]), "brats")])
+    assert torch.equal(d_l, torch.from_numpy(g["m_dice_lits"])) and torch.equal(d_b, torch.from_numpy(g["m_dice_brats"]))

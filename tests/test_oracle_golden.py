@@ -135,3 +135,26 @@ def test_g5_layer_calibration_bit_exact(gold, tag):
     fwd = O.quantized_forward(kw["x"], res.weight, res.bias, torch.tensor(np.float32(res.alpha_act or 1.0)),
                               kw["qlvl_act"], kw["q_act"], kw["stride"], kw["padding"])
     assert torch.equal(fwd, T(g[f"{tag}_fwd_q"]))
+
+
+@pytest.mark.parametrize("tag,psz,ov", [("a", 6, 2), ("b", (6, 12, 6), (2, 0, 3)), ("c", 7, 3)])
+def test_g11_sliding_window_split_and_stitch(gold, tag, psz, ov):
+    """Row f1: patch split / stitch of the reference's evaluation loop, bit for bit."""
+    g = gold("g11_sliding_window.npz")
+    img = torch.from_numpy(g[f"{tag}_img"])
+    patches = O.split_patches(img, psz, ov)
+    assert len(patches) == int(g[f"{tag}_npatch"])
+    assert torch.equal(torch.stack(patches), torch.from_numpy(g[f"{tag}_patches"]))
+    preds = [torch.stack([p * 2.0 + 1.0, p.flip(1) - 0.5]) for p in patches]
+    assert torch.equal(O.stitch_patches(img, preds, psz, ov), torch.from_numpy(g[f"{tag}_stitched"]))
+
+
+def test_g11_dice_helpers(gold):
+    g = gold("g11_sliding_window.npz")
+    logits = torch.from_numpy(g["m_logits"])
+    d_l = torch.stack([d.float() for d in O.dice_vs_label(logits, torch.from_numpy(g["m_tgt_lits"]), "lits")])
+    d_b = torch.stack([d.float() for d in O.dice_vs_label(logits, torch.from_numpy(g["m_tgt_brats"]), "brats")])
+    assert torch.equal(d_l, torch.from_numpy(g["m_dice_lits"]))
+    assert torch.equal(d_b, torch.from_numpy(g["m_dice_brats"]))
+    empty = O.dice(torch.zeros(4, dtype=torch.bool), torch.zeros(4, dtype=torch.bool)).float()
+    assert torch.equal(empty, torch.from_numpy(g["m_dice_empty"]))
