@@ -47,6 +47,17 @@ FP_STATE_BYTES = C.sizeof(FpState)
 _P, _SZ, _I, _F, _D, _LL = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double, C.c_longlong
 _GP = C.POINTER(Geom)
 
+
+class ChainArgs(C.Structure):
+    """effq_chain_args of include/effq_hip.h."""
+    _fields_ = [("B0", C.c_void_p), ("Ainv", C.c_void_p), ("W0", C.c_void_p), ("b0", C.c_void_p),
+                ("G_prev", C.c_void_p), ("dual", C.c_void_p), ("wstar", C.c_void_p), ("bstar", C.c_void_p),
+                ("v", C.c_void_p), ("G", C.c_void_p), ("Gq", C.c_void_p), ("state", C.c_void_p),
+                ("err_flag", C.c_void_p), ("prox_ws", C.c_void_p), ("prox_ws_bytes", C.c_size_t),
+                ("red_ws", C.c_void_p), ("c2", C.c_int32), ("n", C.c_int32), ("has_bias", C.c_int32),
+                ("levels", C.c_int32), ("shift_terms", C.c_int32), ("max_iter", C.c_int32), ("rho", C.c_double),
+                ("eta", C.c_double), ("rho_inv", C.c_double), ("tol", C.c_double), ("dual_div", C.c_float)]
+
 # name -> (restype, argtypes).  Must list every symbol include/effq_hip.h declares.
 SIGNATURES = {
     "effq_last_error": (C.c_char_p, []),
@@ -80,6 +91,7 @@ SIGNATURES = {
     "effq_prox_ws_bytes": (_SZ, [_I, _I]),
     "effq_prox_solve": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _D, _D, _P, _P, _P, _SZ, _P]),
     "effq_prox_solve_shifted": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _D, _D, _D, _I, _P, _P, _P, _SZ, _P]),
+    "effq_admm_chain_step": (_I, [C.POINTER(ChainArgs), _P]),
     "effq_admm_presum": (_I, [_P, _P, _P, _SZ, _P]),
     "effq_admm_project_dual": (_I, [_P, _P, _P, _I, _P, _P, _F, _P, _SZ, _P]),
     "effq_conv_i8_supported": (_I, [_GP, _I, _I]),

@@ -566,4 +566,31 @@ int effq_prox_solve_shifted(const float* B0, const float* Ainv, const float* W0,
                          ws_bytes, stream);
 }
 
+int effq_admm_chain_step(const effq_chain_args* a, void* stream) {
+  EFFQ_CHECK_ARG(a != nullptr && a->state != nullptr && a->err_flag != nullptr && a->v != nullptr && a->G != nullptr);
+  const size_t nw = (size_t)a->c2 * (size_t)(a->n - (a->has_bias ? 1 : 0));
+  if (nw > effq_fp_coop_max()) {
+    set_error("admm_chain_step: %zu weights exceed the single-launch fixed points", nw);
+    return EFFQ_ERR_ARG;
+  }
+  int rc;
+  if (a->shift_terms > 0)
+    rc = effq_prox_solve_shifted(a->B0, a->Ainv, a->W0, a->b0, a->G_prev, a->dual, a->c2, a->n, a->has_bias, a->rho,
+                                 a->eta, a->rho_inv, a->shift_terms, a->wstar, a->bstar, a->prox_ws, a->prox_ws_bytes,
+                                 stream);
+  else
+    rc = effq_prox_solve(a->B0, a->Ainv, a->W0, a->b0, a->G_prev, a->dual, a->c2, a->n, a->has_bias, a->rho, a->eta,
+                         a->wstar, a->bstar, a->prox_ws, a->prox_ws_bytes, stream);
+  if (rc != EFFQ_OK) return rc;
+  if (nw <= effq_fp_small_max())
+    rc = effq_fixed_point_small(a->wstar, a->dual, a->v, nw, a->levels, -1.0, 1.0, a->tol, a->max_iter, a->state, stream);
+  else
+    rc = effq_fixed_point_coop(a->wstar, a->dual, a->v, nw, a->levels, -1.0, 1.0, a->tol, a->max_iter, a->state,
+                               a->red_ws, stream);
+  if (rc != EFFQ_OK) return rc;
+  rc = effq_fp_check(a->state, a->err_flag, stream);
+  if (rc != EFFQ_OK) return rc;
+  return effq_admm_project_dual(a->v, a->wstar, a->state, a->levels, a->G, a->dual, a->dual_div, a->Gq, nw, stream);
+}
+
 }  // extern "C"

@@ -368,12 +368,41 @@ class HipOps:
         c2, n = B0.shape
         ws = self._workspace("prox", self.lib.effq_prox_ws_bytes(c2, n))
         # sweeps for 2^-26: factor <= d/(rho_inv+eta)
-        d = rho_inv - rho
-        terms = 1 if d <= 0 else min(64, max(2, int(math.ceil(-26.0 * math.log(2.0) / math.log(d / (rho_inv + eta))))))
+        terms = self.shift_terms(rho, eta, rho_inv)
         check(self.lib.effq_prox_solve_shifted(_ptr(B0), _ptr(Ainv), _ptr(W0), _ptr(b0), _ptr(G), _ptr(dual), c2, n,
                                                int(b0 is not None), rho, eta, rho_inv, terms, _ptr(wstar),
                                                _ptr(bstar), _ptr(ws), ws.numel(), self.stream),
               "effq_prox_solve_shifted")
+
+    # -- one ADMM chain step per binding call ------------------------------------------------------
+    def chain_supported(self, n_weights: int) -> bool:
+        return n_weights <= self.lib.effq_fp_coop_max() and COOP_FIXED_POINT
+
+    def new_chain(self, B0, W0, b0, dual, wstar, v, err_flag, levels: int, eta: float):
+        """Argument block of effq_admm_chain_step for one layer; the per-iteration fields are set by chain_step."""
+        c2, n = B0.shape
+        a = _lib.ChainArgs()
+        ws = self._workspace("prox", self.lib.effq_prox_ws_bytes(c2, n))
+        a.B0, a.W0, a.b0 = B0.data_ptr(), W0.data_ptr(), (b0.data_ptr() if b0 is not None else None)
+        a.dual, a.wstar, a.v = dual.data_ptr(), wstar.data_ptr(), v.data_ptr()
+        a.err_flag = err_flag.data_ptr()
+        a.prox_ws, a.prox_ws_bytes, a.red_ws = ws.data_ptr(), ws.numel(), self._red_ws.data_ptr()
+        a.c2, a.n, a.has_bias, a.levels = c2, n, int(b0 is not None), int(levels)
+        a.max_iter, a.tol, a.eta = 100 * int(levels), ADMM_TOL, float(eta)
+        a._keep = (B0, W0, b0, dual, wstar, v, err_flag, ws)      # the block holds raw pointers
+        return a
+
+    def chain_step(self, a, Ainv, G_prev, bstar, G, Gq, state, rho: float, dual_div: float, rho_inv: float = 0.0,
+                   shift_terms: int = 0):
+        a.Ainv, a.G_prev = Ainv.data_ptr(), G_prev.data_ptr()
+        a.bstar = bstar.data_ptr() if bstar is not None else None
+        a.G, a.Gq, a.state = G.data_ptr(), (Gq.data_ptr() if Gq is not None else None), state.data_ptr()
+        a.rho, a.rho_inv, a.shift_terms, a.dual_div = float(rho), float(rho_inv), int(shift_terms), float(dual_div)
+        check(self.lib.effq_admm_chain_step(C.byref(a), self.stream), "effq_admm_chain_step")
+
+    def shift_terms(self, rho: float, eta: float, rho_inv: float) -> int:
+        d = rho_inv - rho
+        return 1 if d <= 0 else min(64, max(2, int(math.ceil(-26.0 * math.log(2.0) / math.log(d / (rho_inv + eta))))))
 
     # -- a4 elementwise -------------------------------------------------------------------------
     def admm_presum(self, wstar, dual, v):

@@ -340,6 +340,9 @@ class EfficientQConvHIP(PTQConv):
                     ev.record(side)
                     inv_of[r_] = (buf, ev)
         main_pin = pin(main_s) if (pin is not None and main_s is not None) else None
+        chain = None
+        if hasattr(ops, "new_chain") and ops.chain_supported(W0.numel()):
+            chain = ops.new_chain(B0, W0, b0, dual, wstar, v, fp_err, self.qlvl_w, eta)
         Ainv, rho_of_inv = None, None
         import time as _time
         t_loop0 = _time.perf_counter()
@@ -359,22 +362,27 @@ class EfficientQConvHIP(PTQConv):
             if ev_loss[p_] is not None:             # the loss of iteration i-2 is done with this parity's buffers
                 main_s.wait_event(ev_loss[p_])
             G, Gq, bstar, st_w = Gb[p_], Gqb[p_], bsb[p_], stb[p_]
-            if use_shift:
-                ops.prox_solve_shifted(B0, inv_of[rhos[1]][0], W0, b0, Gb[p_ ^ 1], dual, rho, eta, rhos[1], wstar, bstar)
-            else:
-                ops.prox_solve(B0, Ainv, W0, b0, Gb[p_ ^ 1], dual, rho, eta, wstar, bstar)
-            it_w = ops.weight_fixed_point(wstar, dual, v, self.qlvl_w, st_w, guess)   # (:108) no host sync
-            ops.fp_check(st_w, fp_err)                                                # when the tensor is small
-            if it_w is not None:
-                guess = it_w + 2
-                w_iters.append(it_w)
             dual_div = 1.0
             if i % RHO_PERIOD == 0:                                        # (:129-137)
                 dual_div = 2.0 if rho * 2 <= rho_m else rho_m / rho
-            if int_conv:
-                ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div, Gq)
+            if chain is not None:      # prox -> fixed point -> check -> projection in ONE binding call
+                if use_shift:
+                    ops.chain_step(chain, inv_of[rhos[1]][0], Gb[p_ ^ 1], bstar, G, Gq, st_w, rho, dual_div,
+                                   rhos[1], ops.shift_terms(rho, eta, rhos[1]))
+                else:
+                    ops.chain_step(chain, Ainv, Gb[p_ ^ 1], bstar, G, Gq, st_w, rho, dual_div)
             else:
-                ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div)
+                if use_shift:
+                    ops.prox_solve_shifted(B0, inv_of[rhos[1]][0], W0, b0, Gb[p_ ^ 1], dual, rho, eta, rhos[1], wstar,
+                                           bstar)
+                else:
+                    ops.prox_solve(B0, Ainv, W0, b0, Gb[p_ ^ 1], dual, rho, eta, wstar, bstar)
+                it_w = ops.weight_fixed_point(wstar, dual, v, self.qlvl_w, st_w, guess)   # (:108) no host sync
+                ops.fp_check(st_w, fp_err)                                                # when the tensor is small
+                if it_w is not None:
+                    guess = it_w + 2
+                    w_iters.append(it_w)
+                ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div, Gq if int_conv else None)
 
             def loss_step(i=i, G=G, Gq=Gq, bstar=bstar, st_w=st_w):
                 if use_i8:

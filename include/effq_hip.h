@@ -228,6 +228,26 @@ int conv3d_calib_step_i8s(const uint8_t* xidx_ndhwc, const int8_t* Gq, const flo
 int effq_adam_step(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
                    int t, size_t n, void* stream);
 
+/* ---- one ADMM chain step in ONE call (EfficientQConv.py:104-111,129-137) --------------------------
+ * prox solve -> v = w* + dual and its scale fixed point -> convergence check -> projection + dual update, issued
+ * back to back on `stream`: exactly effq_prox_solve[_shifted] + effq_fixed_point_small/coop + effq_fp_check +
+ * effq_admm_project_dual with the same arguments.  It exists for the host: the small layers of a network are
+ * bound by the ~7 binding calls per iteration, not by the GPU.  shift_terms > 0 selects the shifted solve
+ * (Ainv = A(rho_inv)^-1).  Returns EFFQ_ERR_ARG when the weight tensor is too large for the single-launch
+ * fixed points (caller falls back to the separate entry points). */
+typedef struct effq_chain_args {
+  const float* B0; const float* Ainv; const float* W0; const float* b0;   /* b0 NULL when !has_bias */
+  const float* G_prev;          /* G of the previous iteration */
+  float* dual; float* wstar; float* bstar; float* v;
+  float* G; int8_t* Gq;         /* outputs of the projection (Gq may be NULL) */
+  effq_fp_state* state; int32_t* err_flag;
+  void* prox_ws; size_t prox_ws_bytes; void* red_ws;
+  int32_t c2, n, has_bias, levels, shift_terms, max_iter;
+  double rho, eta, rho_inv, tol;
+  float dual_div;
+} effq_chain_args;
+int effq_admm_chain_step(const effq_chain_args* a, void* stream);
+
 /* ---- f2: bit-packed storage of level ids ---------------------------------------------------
  * The reference stores one uint8 per weight (store_int_weight, PTQConv.py:125-152); these pack the level ids
  * at 1/2/4/8 bits each (little-endian bit stream: element i in bits [i*bits, (i+1)*bits)) and back. */

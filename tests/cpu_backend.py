@@ -119,7 +119,7 @@ class OracleOps:
     def admm_presum(self, wstar, dual, v):
         v.copy_(wstar + dual)
 
-    def admm_project_dual(self, v, wstar, state, levels, G, dual, dual_div):
+    def admm_project_dual(self, v, wstar, state, levels, G, dual, dual_div, Gq=None):
         a = state[0].item()
         b = O.discretize(v.double() / a, levels, -1.0, 1.0).float()
         g = a * b
