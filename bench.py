@@ -284,7 +284,7 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
         "wall_clock_s_per_calibration": round(dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "i8xi8->i32 (exact) for the per-iteration loss convs of 32/64-channel 3^3 layers, f32/f64 elsewhere"
+        "dtype": "i8xi8->i32 (exact) for the Gram systems and per-iteration loss convs of the layers with quantised input, f32/f64 elsewhere"
                  if exact else "f32", "data": "synthetic",
         "config": {"workload": f"BraTS 3D-UNet fp32->{a.levels}-level PTQ (qlvl_w={a.levels} qlvl_a={a.levels}, "
                                f"q_first=q_last=256,-1), 22 quantised convs, 200 ADMM its/layer, "
