@@ -318,7 +318,7 @@ __global__ __launch_bounds__(T) void k_fp_small(const float* __restrict__ a, con
 }
 
 // ---- cooperative whole-fixed-point kernel for larger tensors --------------------------------------
-// G <= 64 workgroups of 1024 threads, one per CU, each owning a contiguous slice of v that stays in LDS for
+// G <= 256 workgroups of 1024 threads, one per CU, each owning a contiguous slice of v that stays in LDS for
 // all iterations.  Per iteration every workgroup publishes its two partial sums, all meet at a grid
 // barrier, and EVERY workgroup adds the G partials in workgroup order (identical alpha everywhere, run-to-
 // run and rank-to-rank deterministic -- replicated data-parallel ranks must stay bit-identical).
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(T) void k_fp_small(const float* __restrict__ a, con
 // Every spin is bounded: on time-out the state is marked done=3 and all workgroups leave.
 constexpr int FPC_T = 1024;
 constexpr int FPC_SLICE = 27648;          // floats per workgroup kept in LDS (108 KiB)
-constexpr int FPC_MAXG = 64;
+constexpr int FPC_MAXG = 256;          // one workgroup per CU at most: 7.08 M values = 512 x 512 x 27 weights
 constexpr unsigned FPC_SPIN_LIMIT = 1u << 24;
 
 __device__ __forceinline__ bool fpc_barrier(unsigned int* counter, unsigned target, int* s_fail) {

@@ -486,7 +486,7 @@ def test_short_k_exact_int_conv_rejects_what_it_cannot_do(ops):
     assert not ops.conv_i8s_supported(make_geom((1, 4, 8, 8, 8), 32, 3, 2, 1), 4, 300)
 
 
-@pytest.mark.parametrize("n,L", [(40000, 4), (110592, 4), (442368, 16), (1769472, 4), (300001, 256)])
+@pytest.mark.parametrize("n,L", [(40000, 4), (110592, 4), (442368, 16), (1769472, 4), (300001, 256), (7077888, 4)])
 def test_cooperative_weight_fixed_point_matches_oracle(ops, n, L):
     """effq_fixed_point_coop (several workgroups, grid barrier per iteration): same alpha / iteration count as the
     fp64 oracle, v = w* + dual formed on the fly, identical on repetition (deterministic combination order)."""
