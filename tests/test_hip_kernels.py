@@ -522,3 +522,47 @@ def test_bit_packed_level_storage_round_trip(ops, bits, levels, n):
         want[(i * bits) // 8] |= np.uint8((int(v) << ((i * bits) % 8)) & 0xFF)
     assert np.array_equal(packed.cpu().numpy(), want)
     assert torch.equal(ops.unpack_levels(packed, n, bits).cpu(), idx)
+
+
+@pytest.mark.parametrize("c2,c1k,L,shift", [(32, 864, 4, False), (16, 108, 256, False), (64, 64, 16, True), (128, 3456, 4, False)])
+def test_chain_step_equals_the_separate_entry_points(ops, c2, c1k, L, shift):
+    """effq_admm_chain_step = effq_prox_solve[_shifted] + effq_fixed_point_small/coop + effq_fp_check +
+    effq_admm_project_dual issued from one binding call: bit-identical outputs."""
+    gen = torch.Generator().manual_seed(c2 + c1k + L)
+    n = c1k + 1
+    X = torch.randn(n, 2 * n, generator=gen)
+    A0 = dev((2 * X @ X.T).float())
+    rho, eta = 20.0, 1.0
+    Ainv = ops.spd_inverse(A0, True, 2 * rho if shift else rho, eta)
+    B0 = dev(torch.randn(c2, n, generator=gen) * 5)
+    W0 = dev(torch.randn(c2, c1k, generator=gen) * 0.1)
+    b0 = dev(torch.randn(c2, generator=gen) * 0.1)
+    Gp = dev(torch.randn(c2, c1k, generator=gen) * 0.1)
+    dual0 = dev(torch.randn(c2, c1k, generator=gen) * 0.01)
+    outs = []
+    for fused in (False, True):
+        dual = dual0.clone()
+        wstar, v, G = torch.empty_like(W0), torch.empty_like(W0), torch.empty_like(W0)
+        bstar = torch.empty(c2, device="cuda:0")
+        Gq = torch.empty(W0.shape, dtype=torch.int8, device="cuda:0")
+        st = ops.new_fp_state()
+        err = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        if fused:
+            ch = ops.new_chain(B0, W0, b0, dual, wstar, v, err, L, eta)
+            if shift:
+                ops.chain_step(ch, Ainv, Gp, bstar, G, Gq, st, rho, 2.0, 2 * rho, ops.shift_terms(rho, eta, 2 * rho))
+            else:
+                ops.chain_step(ch, Ainv, Gp, bstar, G, Gq, st, rho, 2.0)
+        else:
+            if shift:
+                ops.prox_solve_shifted(B0, Ainv, W0, b0, Gp, dual, rho, eta, 2 * rho, wstar, bstar)
+            else:
+                ops.prox_solve(B0, Ainv, W0, b0, Gp, dual, rho, eta, wstar, bstar)
+            assert ops.weight_fixed_point(wstar, dual, v, L, st) is None
+            ops.fp_check(st, err)
+            ops.admm_project_dual(v, wstar, st, L, G, dual, 2.0, Gq)
+        assert err.item() == 0
+        outs.append((wstar.cpu(), bstar.cpu(), v.cpu(), G.cpu(), Gq.cpu(), dual.cpu(), ops.read_fp_state(st)))
+    for a, b in zip(outs[0][:-1], outs[1][:-1]):
+        assert torch.equal(a, b)
+    assert outs[0][-1] == outs[1][-1]
