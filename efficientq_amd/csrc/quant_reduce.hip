@@ -490,7 +490,10 @@ __global__ __launch_bounds__(TPB) void k_presum(const float* __restrict__ a, con
 __global__ __launch_bounds__(TPB) void k_project_dual(const float* __restrict__ v, const float* __restrict__ wstar,
                                                       const effq_fp_state* __restrict__ st, double d,
                                                       float* __restrict__ G, float* __restrict__ dual,
-                                                      float dual_div, int8_t* __restrict__ Gq, int lm1, size_t n) {
+                                                      float dual_div, int8_t* __restrict__ Gq, int lm1, size_t n,
+                                                      int32_t* __restrict__ err_flag) {
+  // (optional) the convergence check of the fixed point that produced `st`, folded in to save a launch
+  if (err_flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && st->done != 1) *err_flag = (st->done == 2) ? 2 : 3;
   const double alpha = st->alpha;
   const float alpha32 = (float)alpha;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -763,16 +766,22 @@ int effq_admm_presum(const float* wstar, const float* dual, float* v, size_t n, 
   return EFFQ_OK;
 }
 
-int effq_admm_project_dual(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
-                           float* dual, float dual_div, int8_t* Gq_out, size_t n, void* stream) {
+int effq_project_dual_checked(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
+                              float* dual, float dual_div, int8_t* Gq_out, size_t n, int32_t* err_flag_dev,
+                              void* stream) {
   EFFQ_CHECK_ARG(v && wstar && state_dev && G && dual && levels >= 2 && dual_div > 0.0f);
   EFFQ_CHECK_ARG(Gq_out == nullptr || levels <= 256);
   if (n == 0) return EFFQ_OK;
   const double d = 2.0 / (double)(levels - 1);
   hipLaunchKernelGGL(k_project_dual, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
-                     G, dual, dual_div, Gq_out, levels - 1, n);
+                     G, dual, dual_div, Gq_out, levels - 1, n, err_flag_dev);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
+}
+
+int effq_admm_project_dual(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
+                           float* dual, float dual_div, int8_t* Gq_out, size_t n, void* stream) {
+  return effq_project_dual_checked(v, wstar, state_dev, levels, G, dual, dual_div, Gq_out, n, nullptr, stream);
 }
 
 int effq_admm_keep_best(const double* sqerr_dev, double* best_dev, int iter, const float* G, const float* b,

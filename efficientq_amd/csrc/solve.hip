@@ -566,6 +566,10 @@ int effq_prox_solve_shifted(const float* B0, const float* Ainv, const float* W0,
                          ws_bytes, stream);
 }
 
+int effq_project_dual_checked(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
+                              float* dual, float dual_div, int8_t* Gq_out, size_t n, int32_t* err_flag_dev,
+                              void* stream);   // quant_reduce.hip (internal to the library)
+
 int effq_admm_chain_step(const effq_chain_args* a, void* stream) {
   EFFQ_CHECK_ARG(a != nullptr && a->state != nullptr && a->err_flag != nullptr && a->v != nullptr && a->G != nullptr);
   const size_t nw = (size_t)a->c2 * (size_t)(a->n - (a->has_bias ? 1 : 0));
@@ -588,9 +592,9 @@ int effq_admm_chain_step(const effq_chain_args* a, void* stream) {
     rc = effq_fixed_point_coop(a->wstar, a->dual, a->v, nw, a->levels, -1.0, 1.0, a->tol, a->max_iter, a->state,
                                a->red_ws, stream);
   if (rc != EFFQ_OK) return rc;
-  rc = effq_fp_check(a->state, a->err_flag, stream);
-  if (rc != EFFQ_OK) return rc;
-  return effq_admm_project_dual(a->v, a->wstar, a->state, a->levels, a->G, a->dual, a->dual_div, a->Gq, nw, stream);
+  // the convergence check rides in the projection kernel (one launch less than effq_fp_check + project_dual)
+  return effq_project_dual_checked(a->v, a->wstar, a->state, a->levels, a->G, a->dual, a->dual_div, a->Gq, nw,
+                                   a->err_flag, stream);
 }
 
 }  // extern "C"
