@@ -686,7 +686,8 @@ int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* 
     p.debug = dbg ? atoi(dbg) : 0;
   }
   hipStream_t st = as_stream(stream);
-  if (y_fp != nullptr) EFFQ_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned int), st));
+  // (the ticket of the last-block reduction is left at zero by the kernel that used it: the caller zero-fills
+  //  the workspace once, effq_hip.h)
   // loss-only calls of the short-K layers go to the direct-gather kernels
   const int dkind = (out == nullptr && att == nullptr && !p.act_on && y_fp != nullptr && getenv("EFFQ_NO_DIRECT") == nullptr)
                         ? conv_direct_kind(g) : 0;

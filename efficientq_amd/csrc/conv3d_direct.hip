@@ -9,6 +9,7 @@
 //     lanes share a voxel (one coalesced 16-byte load each), partial dot products are reduced with DPP shuffles.
 // Both end in the deterministic last-block reduction of common.h and write [sum d^2, sum d^2] like the tiled path.
 #include <stdint.h>
+#include <stdlib.h>
 #include "common.h"
 #include "conv_direct.h"
 
@@ -149,7 +150,10 @@ int conv_direct_launch(int kind, DirectParams& p, size_t max_blocks, hipStream_t
   p.ntiles = (int)((p.V + 31) / 32);
   if (kind == 1) {
     size_t grid = ((size_t)p.ntiles + 3) / 4;
-    if (grid > 768) grid = 768;               // 3 workgroups (12 waves) per CU, grid-stride over the tiles
+    static const size_t cap = getenv("EFFQ_C4_GRID") ? (size_t)atoi(getenv("EFFQ_C4_GRID")) : 512;   // tuning aid
+    // 2 workgroups per CU (3 are 5 % faster alone): the 164-VGPR waves then leave room for the scale fixed point
+    // of the next ADMM iteration to run beside this kernel instead of queueing behind it (first-conv layer 135 -> 122 ms)
+    if (grid > cap) grid = cap;
     if (grid > max_blocks) grid = max_blocks;
     hipLaunchKernelGGL(k_conv3d_c4, dim3((unsigned)grid), dim3(256), 0, st, p);
     return EFFQ_OK;

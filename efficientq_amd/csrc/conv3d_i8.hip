@@ -610,7 +610,8 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
     p.debug = dbg ? atoi(dbg) : 0;
   }
   hipStream_t st = as_stream(stream);
-  EFFQ_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned int), st));
+  // (the ticket of the last-block reduction is left at zero by the kernel that used it: the caller zero-fills
+  //  the workspace once, effq_hip.h)
   {
     size_t nb = (pl.wq_bytes + 255) / 256;
     if (nb > 2048) nb = 2048;

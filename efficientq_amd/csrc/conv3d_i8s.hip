@@ -376,7 +376,8 @@ int conv3d_calib_step_i8s(const uint8_t* xidx_ndhwc, const int8_t* Gq, const flo
     if (rc != EFFQ_OK) return rc;
     EFFQ_LAUNCH_CHECK();
   }
-  EFFQ_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned int), st));
+  // (the ticket of the last-block reduction is left at zero by the kernel that used it: the caller zero-fills
+  //  the workspace once, effq_hip.h)
   {
     size_t nb = (pl.wq_bytes + 255) / 256;
     if (nb > 64) nb = 64;

@@ -351,7 +351,8 @@ __device__ __forceinline__ bool fpc_barrier(unsigned int* counter, unsigned targ
   return *s_fail == 0;
 }
 
-__global__ __launch_bounds__(FPC_T) void k_fp_coop(const float* __restrict__ a, const float* __restrict__ b2,
+template <int T>
+__global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, const float* __restrict__ b2,
                                                    float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
                                                    double hi, double d, double tol, int max_iter, double* partials,
                                                    unsigned int* counter) {
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(FPC_T) void k_fp_coop(const float* __restrict__ a, 
   const int cnt = (s1 > s0) ? (int)(s1 - s0) : 0;
   if (tid == 0) s_fail = 0;
   double acc[2] = {0.0, 0.0};
-  for (int i = tid; i < cnt; i += FPC_T) {
+  for (int i = tid; i < cnt; i += T) {
     const float v = (b2 != nullptr) ? (a[s0 + i] + b2[s0 + i]) : a[s0 + i];
     if (v_out != nullptr) v_out[s0 + i] = v;
     vs[i] = v;
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(FPC_T) void k_fp_coop(const float* __restrict__ a, 
     const int par = (it + 1) & 1;          // parity 0 was used by the abs-sum epoch
     acc[0] = acc[1] = 0.0;
     const double ralpha = 1.0 / alpha, rd = 1.0 / d;
-    for (int i = tid; i < cnt; i += FPC_T) {
+    for (int i = tid; i < cnt; i += T) {
       const double v = (double)vs[i];
       double r;
       const double bq = disc64_fast(v, alpha, ralpha, lo, hi, d, rd, &r);
@@ -517,23 +518,30 @@ __global__ __launch_bounds__(TPB) void k_keep_best(const double* __restrict__ sq
                                                    size_t nb) {
   // every thread evaluates the same predicate from the same two doubles (EfficientQConv.py:139-142)
   const double loss = sqerr[0];
-  const double cur = best[0];
+  const double cur = __hip_atomic_load(&best[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const bool take = (iter == 0) || (loss < cur);
-  if (!take) return;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (size_t i = t0; i < nw; i += stride) bG[i] = G[i];
-  if (b != nullptr)
-    for (size_t i = t0; i < nb; i += stride) bb[i] = b[i];
-  // best[0] is rewritten by a follow-up single-thread kernel (k_commit_best) so that all blocks
-  // of this launch see the same old value
-}
-
-__global__ void k_commit_best(const double* sqerr, double* best, int iter) {
-  const double loss = sqerr[0];
-  if (iter == 0 || loss < best[0]) {
-    best[0] = loss;
-    best[1] = (double)iter;
+  if (take) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = t0; i < nw; i += stride) bG[i] = G[i];
+    if (b != nullptr)
+      for (size_t i = t0; i < nb; i += stride) bb[i] = b[i];
+  }
+  // best[0..1] are rewritten by the LAST block to get here (ticket in best[2]), i.e. after every block has read
+  // the old value: no follow-up kernel (this runs 200 times per layer on the loss stream, where every launch counts)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(best + 2);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (take) {
+        __hip_atomic_store(&best[0], loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        best[1] = (double)iter;
+      }
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -724,31 +732,53 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
 
 size_t effq_fp_coop_max(void) { return (size_t)FPC_SLICE * FPC_MAXG; }
 
-int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
-                          double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream) {
+// light != 0: workgroups of 512 threads with slices of at most 13824 values (54 KB of LDS): a footprint that fits
+// beside two workgroups of the loss conv on a CU, so the fixed point of iteration i+1 runs DURING the loss conv of
+// iteration i instead of queueing behind it (a 1024-thread single-workgroup fixed point cannot be placed before
+// the persistent conv workgroups retire).
+static int fixed_point_coop_impl(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                                 double tol, int max_iter, effq_fp_state* state_dev, void* ws, int light, void* stream) {
   EFFQ_CHECK_ARG(a && state_dev && ws && n > 0 && levels >= 2 && hi > lo && max_iter > 0);
   EFFQ_CHECK_ARG(n <= effq_fp_coop_max());
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
   const double d = (hi - lo) / (double)(levels - 1);
-  int G = (int)((n + FPC_SLICE - 1) / FPC_SLICE);
+  const size_t slice = light ? (size_t)FPC_SLICE / 2 : (size_t)FPC_SLICE;
+  int G = (int)((n + slice - 1) / slice);
   if (G < 1) G = 1;
+  EFFQ_CHECK_ARG(G <= FPC_MAXG);
   const size_t per = (n + G - 1) / G;
   const size_t lds = per * sizeof(float);
-  // workspace: reuse the reduction workspace: partials [2][64][2] doubles at its start, counter after them
+  // workspace: reuse the reduction workspace: partials [2][FPC_MAXG][2] doubles at its start, counter after them
   double* partials = reinterpret_cast<double*>(ws);
   unsigned int* counter = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(ws) + 2 * FPC_MAXG * 2 * sizeof(double));
   hipStream_t st = as_stream(stream);
   EFFQ_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), st));
   static bool attr_set = false;
   if (!attr_set) {
-    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fp_coop), hipFuncAttributeMaxDynamicSharedMemorySize,
+    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fp_coop<FPC_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(FPC_SLICE * sizeof(float))));
+    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fp_coop<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(FPC_SLICE * sizeof(float))));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_fp_coop, dim3(G), dim3(FPC_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol, max_iter,
-                     partials, counter);
+  if (light)
+    hipLaunchKernelGGL(k_fp_coop<512>, dim3(G), dim3(512), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol, max_iter,
+                       partials, counter);
+  else
+    hipLaunchKernelGGL(k_fp_coop<FPC_T>, dim3(G), dim3(FPC_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol,
+                       max_iter, partials, counter);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
+}
+
+int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                          double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream) {
+  return fixed_point_coop_impl(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, ws, 0, stream);
+}
+
+int effq_fixed_point_coop_light(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                                double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream) {
+  return fixed_point_coop_impl(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, ws, 1, stream);
 }
 
 int effq_fp_check(const effq_fp_state* state_dev, int32_t* err_flag_dev, void* stream) {
@@ -790,8 +820,6 @@ int effq_admm_keep_best(const double* sqerr_dev, double* best_dev, int iter, con
   EFFQ_CHECK_ARG((b == nullptr) == (best_b == nullptr));
   hipLaunchKernelGGL(k_keep_best, dim3(stream_grid(nw)), dim3(TPB), 0, as_stream(stream), sqerr_dev, best_dev, iter,
                      G, b, best_G, best_b, nw, nb);
-  EFFQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_commit_best, dim3(1), dim3(1), 0, as_stream(stream), sqerr_dev, best_dev, iter);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

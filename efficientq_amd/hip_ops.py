@@ -450,6 +450,8 @@ class HipOps:
         return sqerr
 
     def admm_keep_best(self, sqerr, best, it: int, G, b, best_G, best_b):
+        if best.numel() < 4:
+            raise _lib.EffqError("admm_keep_best: best_dev holds 4 doubles (loss, iteration, ticket, spare)")
         check(self.lib.effq_admm_keep_best(_ptr(sqerr), _ptr(best), it, _ptr(G), _ptr(b), _ptr(best_G), _ptr(best_b),
                                            G.numel(), 0 if b is None else b.numel(), self.stream),
               "effq_admm_keep_best")

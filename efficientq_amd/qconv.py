@@ -299,7 +299,7 @@ class EfficientQConvHIP(PTQConv):
         best_G = torch.empty_like(W0)
         best_b = torch.empty(c2, **f32) if has_b else None
         sqerr = torch.zeros(2, dtype=torch.float64, device=dev)
-        best = torch.zeros(2, dtype=torch.float64, device=dev)
+        best = torch.zeros(4, dtype=torch.float64, device=dev)
         stb = [ops.new_fp_state(), ops.new_fp_state()]
         Gqb = [torch.empty(W0.shape, dtype=torch.int8, device=dev) for _ in range(2)] if int_conv else [None, None]
         fp_err = torch.zeros(1, dtype=torch.int32, device=dev)

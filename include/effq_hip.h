@@ -180,7 +180,8 @@ int effq_admm_project_dual(const float* v, const float* wstar, const effq_fp_sta
 /* Gq_out (optional, levels <= 128): signed level numerators j' = 2*level-(L-1), so that G = alpha_w*j'/(L-1);
  * the operand of the exact-integer conv below. */
 /* Best-iterate bookkeeping on the device: if (iter==0 || loss<best_loss) copy G,b into best_G,best_b.
- * loss_dev = {sum sq err (double)}; best_dev = {best loss (double), best iter (as double)}. */
+ * loss_dev = {sum sq err (double)}; best_dev = FOUR doubles, zero-initialised by the caller: {best loss, best iter
+ * (as double), ticket word of the kernel, spare}. */
 int effq_admm_keep_best(const double* sqerr_dev, double* best_dev, int iter, const float* G, const float* b,
                         float* best_G, float* best_b, size_t nw, size_t nb, void* stream);
 
@@ -191,7 +192,8 @@ int effq_admm_keep_best(const double* sqerr_dev, double* best_dev, int iter, con
  * y_fp may be NULL (plain forward), out may be NULL (loss only), att may be NULL (sqerr[1]=sqerr[0]).
  * If act_alpha_dev != NULL the fp32 quant-dequant of PTQConv._quantize_act (levels act_levels,
  * range [0,1]) is applied to x while staging it (quantised forward, PTQConv.py:163-167).
- * ws: effq_conv_ws_bytes(geom). */
+ * ws: effq_conv_ws_bytes(geom) bytes, ZERO-FILLED once by the caller (it holds the ticket of the last-block
+ * reduction, which every launch leaves at zero again; the same holds for the i8 conv workspaces below). */
 size_t effq_conv_ws_bytes(const effq_geom* g);
 int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* bias, const float* y_fp,
                             const float* att, const effq_geom* g, const float* act_alpha_dev, int act_levels,

@@ -19,7 +19,7 @@ for c in (32, 64, 128, 256):
     v = torch.empty_like(W); G = torch.empty_like(W); Gq = torch.empty(W.shape, dtype=torch.int8, device=dev)
     st = ops.new_fp_state()
     bst = torch.zeros(c, device=dev); bG = torch.empty_like(W); bb = torch.empty(c, device=dev)
-    sq = torch.ones(2, dtype=torch.float64, device=dev); best = torch.zeros(2, dtype=torch.float64, device=dev)
+    sq = torch.ones(2, dtype=torch.float64, device=dev); best = torch.zeros(4, dtype=torch.float64, device=dev)
     t_fp = timeit(lambda: ops.weight_fixed_point(W, dual, v, 4, st, 16))
     its = ops.read_fp_state(st)[1]
     d2 = dual.clone()
