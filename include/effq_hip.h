@@ -108,7 +108,7 @@ int effq_alpha_fixed_point(const float* x, size_t n, int levels, double lo, doub
 size_t effq_fp_small_max(void);
 int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                            double tol, int max_iter, effq_fp_state* state_dev, void* stream);
-/* Same contract for larger tensors (n <= effq_fp_coop_max()): one COOPERATIVE launch of ceil(n/27648) <= 64
+/* Same contract for larger tensors (n <= effq_fp_coop_max()): one COOPERATIVE launch of ceil(n/27648) <= 256
  * workgroups (one per CU, slice of v resident in LDS) that meet at a bounded-spin grid barrier once per
  * iteration; partial sums are combined in workgroup order by every workgroup (deterministic).  state.done = 3
  * reports a barrier time-out.  ws: the reduction workspace (effq_reduce_ws_bytes()). */
