@@ -520,11 +520,178 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
                      gridDim.x * gridDim.y);
 }
 
+// Two-plane variant of k_conv3d_i8l: a workgroup tile is 8x4x8 output voxels, wave w owns d-planes w and w+4 and
+// feeds BOTH accumulators from one read of the B operand (the LDS operand traffic limits k_conv3d_i8l: 27 x 2 KB
+// per wave-tile); barriers, tile decoding and halo overlap are amortised over twice the voxels.  2 workgroups/CU.
+constexpr int L2_TD = 8;
+constexpr int L2_HD = L2_TD + 2, L2_NH = L2_HD * I_HH * I_HW;    // 600 halo voxels
+__global__ __launch_bounds__(256, 2) void k_conv3d_i8l2(ConvI8Params p) {
+  constexpr int VS = 48;
+  constexpr int NHL = (L2_NH * 2 + 255) / 256;   // 5
+  __shared__ __attribute__((aligned(16))) int8_t wl[27 * 2 * 32 * 16];
+  __shared__ __attribute__((aligned(16))) int8_t halo[L2_NH * VS];
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ch0 = blockIdx.y * 32;
+  const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per;
+  const int t_end = (t_begin + per < p.ntiles) ? t_begin + per : p.ntiles;
+
+  for (int u = tid; u < 27 * 2 * 32; u += 256) {
+    const int j = u & 31, h = (u >> 5) & 1, tap = u >> 6;
+    *reinterpret_cast<v4i*>(&wl[u * 16]) =
+        *reinterpret_cast<const v4i*>(p.wq + ((size_t)(tap * p.c2p + ch0 + j) * 32 + 16 * h));
+  }
+  const float scale = (float)((double)(*p.act_alpha) * (double)(float)p.wstate->alpha * p.inv_levels);
+  const float bv = (p.bias != nullptr) ? p.bias[ch0 + li] : 0.0f;
+
+  struct Tile {
+    int n, od0, oh0, ow0;
+  };
+  auto decode = [&](int tile) {           // p.tiles_d counts 8-plane tiles for this kernel
+    Tile r;
+    int t = tile;
+    r.ow0 = (t % p.tiles_w) * ITW;
+    t /= p.tiles_w;
+    r.oh0 = (t % p.tiles_h) * ITH;
+    t /= p.tiles_h;
+    r.od0 = (t % p.tiles_d) * L2_TD;
+    r.n = t / p.tiles_d;
+    return r;
+  };
+  int hcd[NHL], hch[NHL], hcw[NHL];
+#pragma unroll
+  for (int k = 0; k < NHL; ++k) {
+    const int u = tid + k * 256;
+    const int vox = (u < L2_NH * 2) ? (u >> 1) : 0;
+    hcw[k] = vox % I_HW;
+    const int t2 = vox / I_HW;
+    hch[k] = t2 % I_HH;
+    hcd[k] = (u < L2_NH * 2) ? (t2 / I_HH) : (1 << 20);
+  }
+  const int part16 = (tid & 1) * 16;
+
+  struct Regs {
+    v4i h[NHL];
+    float y[2][16];
+    unsigned hmask, ymask[2];
+  };
+  auto fetch = [&](int tile, Regs& R) {
+    const Tile tl = decode(tile);
+    const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
+    const size_t nbase = (size_t)tl.n * p.D;
+    unsigned hm = 0;
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int id = id0 + hcd[k], ih = ih0 + hch[k], iw = iw0 + hcw[k];
+      const bool ok = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+      const int cd = min(max(id, 0), p.D - 1), chh = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
+      hm |= (ok ? 1u : 0u) << k;
+      R.h[k] = *reinterpret_cast<const v4i*>(p.x + (((nbase + cd) * p.H + chh) * p.W + cw) * 32 + part16);
+    }
+    R.hmask = hm;
+    unsigned rowok = 0, colok = 0;
+    size_t rowrel[4];
+    int coloff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oh = tl.oh0 + q, ow = tl.ow0 + q + 4 * lh;
+      rowok |= (unsigned)(oh < p.OH) << q;
+      colok |= (unsigned)(ow < p.OW) << q;
+      rowrel[q] = (size_t)min(oh, p.OH - 1) * p.OW * p.C2;
+      coloff[q] = min(ow, p.OW - 1) * p.C2 + ch0 + li;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const int odr = tl.od0 + wid + 4 * pl;
+      const int od = min(odr, p.OD - 1);
+      const bool dok = odr < p.OD;
+      const size_t ybase = (((size_t)tl.n * p.OD + od) * p.OH) * p.OW * p.C2;
+      unsigned ym = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        R.y[pl][r] = p.y[ybase + rowrel[r >> 2] + coloff[r & 3]];
+        ym |= (((rowok >> (r >> 2)) & (colok >> (r & 3)) & 1u) & (dok ? 1u : 0u)) << r;
+      }
+      R.ymask[pl] = ym;
+    }
+  };
+
+  const int hv0 = (wid * I_HH + (li >> 3)) * I_HW + (li & 7);
+  const int hv1 = hv0 + 4 * I_HH * I_HW;
+  double l0 = 0.0;
+  auto body = [&](int tile, Regs& X, bool more) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      const v4i val = ((X.hmask >> k) & 1u) ? X.h[k] : v4i{0, 0, 0, 0};
+      if (u < L2_NH * 2) *reinterpret_cast<v4i*>(&halo[(u >> 1) * VS + (u & 1) * 16]) = val;
+    }
+    float ycur[2][16];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ycur[pl][r] = X.y[pl][r];
+    const unsigned ym0 = X.ymask[0], ym1 = X.ymask[1];
+    __syncthreads();
+    fetch(more ? tile + 2 : tile, X);
+    __builtin_amdgcn_sched_barrier(0);
+    v16i acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const int toff = ((kd * I_HH + kh) * I_HW + kw) * VS + 16 * lh;
+      const v4i b = *reinterpret_cast<const v4i*>(&wl[((tap * 2 + lh) * 32 + li) * 16]);
+      const v4i a0 = *reinterpret_cast<const v4i*>(halo + hv0 * VS + toff);
+      const v4i a1 = *reinterpret_cast<const v4i*>(halo + hv1 * VS + toff);
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d0 = ((float)acc0[r] * scale + bv) - ycur[0][r];
+      const float d1 = ((float)acc1[r] * scale + bv) - ycur[1][r];
+      l0 += ((ym0 >> r) & 1u) ? (double)(d0 * d0) : 0.0;
+      l0 += ((ym1 >> r) & 1u) ? (double)(d1 * d1) : 0.0;
+    }
+  };
+
+  Regs A, B;
+#pragma unroll
+  for (int k = 0; k < NHL; ++k) A.h[k] = B.h[k] = v4i{0, 0, 0, 0};
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) A.y[pl][r] = B.y[pl][r] = 0.0f;
+  A.hmask = B.hmask = 0;
+  A.ymask[0] = A.ymask[1] = B.ymask[0] = B.ymask[1] = 0;
+  if (t_begin < t_end) fetch(t_begin, A);
+  if (t_begin + 1 < t_end) fetch(t_begin + 1, B);
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    body(tile, A, tile + 2 < t_end);
+    if (tile + 1 < t_end) body(tile + 1, B, tile + 3 < t_end);
+  }
+  double v[2] = {l0, l0};
+  grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
+                     gridDim.x * gridDim.y);
+}
+
 struct I8Plan {
   ConvI8Params p;
   dim3 grid;
   size_t nblk, wq_bytes;
 };
+
+static bool i8_two_plane(const effq_geom* g) {
+  static const int on = getenv("EFFQ_I8L2") ? atoi(getenv("EFFQ_I8L2")) : 1;
+  return on != 0 && g->C1 == 32;
+}
 
 static int i8_plan(const effq_geom* g, I8Plan* pl) {
   EFFQ_CHECK_ARG(g != nullptr);
@@ -538,14 +705,15 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
   p.PD = g->PD; p.PH = g->PH; p.PW = g->PW;
   p.OD = g->D + 2 * g->PD - 2; p.OH = g->H + 2 * g->PH - 2; p.OW = g->W + 2 * g->PW - 2;
   EFFQ_CHECK_ARG(p.OD > 0 && p.OH > 0 && p.OW > 0);
-  p.tiles_d = (p.OD + ITD - 1) / ITD;
+  const int td = i8_two_plane(g) ? L2_TD : ITD;
+  p.tiles_d = (p.OD + td - 1) / td;
   p.tiles_h = (p.OH + ITH - 1) / ITH;
   p.tiles_w = (p.OW + ITW - 1) / ITW;
   const long long nt = (long long)p.N * p.tiles_d * p.tiles_h * p.tiles_w;
   EFFQ_CHECK_ARG(nt < (1ll << 30));
   p.ntiles = (int)nt;
   const int ny = p.C2 / 32;
-  const int wg_per_cu = (g->C1 == 32) ? 3 : (g->C1 == 128) ? 2 : 1;
+  const int wg_per_cu = (g->C1 == 32) ? (i8_two_plane(g) ? 2 : 3) : (g->C1 == 128) ? 2 : 1;
   int gx = (256 * wg_per_cu + ny - 1) / ny;
   if (gx < 32) gx = 32;
   if (gx > p.ntiles) gx = p.ntiles;
@@ -622,7 +790,9 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
     EFFQ_LAUNCH_CHECK();
   }
   if (p.C1 == 32) {
-    if (getenv("EFFQ_I8_REGS") != nullptr)      // register-resident variant kept for A/B comparison
+    if (i8_two_plane(g))
+      hipLaunchKernelGGL(k_conv3d_i8l2, pl.grid, dim3(256), 0, st, p);
+    else if (getenv("EFFQ_I8_REGS") != nullptr)      // register-resident variant kept for A/B comparison
       hipLaunchKernelGGL(k_conv3d_i8<1>, pl.grid, dim3(256), 0, st, p);
     else
       hipLaunchKernelGGL(k_conv3d_i8l, pl.grid, dim3(256), 0, st, p);
