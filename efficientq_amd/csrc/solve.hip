@@ -590,9 +590,10 @@ int effq_admm_chain_step(const effq_chain_args* a, void* stream) {
                          a->wstar, a->bstar, a->prox_ws, a->prox_ws_bytes, stream);
   if (rc != EFFQ_OK) return rc;
   static const int light_lo = getenv("EFFQ_FP_LIGHT_MIN") ? atoi(getenv("EFFQ_FP_LIGHT_MIN")) : 8192;   // tuning aid
-  if (nw > (size_t)light_lo && nw <= effq_fp_small_max())
-    // mid-size tensors (the 32-channel 3^3 layers): small-footprint cooperative variant that co-resides with the
-    // overlapped loss conv (quant_reduce.hip)
+  static const int light_hi = getenv("EFFQ_FP_LIGHT_MAX") ? atoi(getenv("EFFQ_FP_LIGHT_MAX")) : 131072;   // tuning aid
+  if (nw > (size_t)light_lo && nw <= (size_t)light_hi)
+    // mid-size tensors (the 32- and 64-channel 3^3 layers): small-footprint cooperative variant that co-resides with
+    // the overlapped loss conv (quant_reduce.hip)
     rc = effq_fixed_point_coop_light(a->wstar, a->dual, a->v, nw, a->levels, -1.0, 1.0, a->tol, a->max_iter, a->state,
                                      a->red_ws, stream);
   else if (nw <= effq_fp_small_max())
