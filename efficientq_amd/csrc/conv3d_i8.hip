@@ -714,7 +714,8 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
   p.ntiles = (int)nt;
   const int ny = p.C2 / 32;
   static const int wpc1 = getenv("EFFQ_I8_WPC") ? atoi(getenv("EFFQ_I8_WPC")) : 3;   // tuning aid (one-plane kernel)
-  const int wg_per_cu = (g->C1 == 32) ? (i8_two_plane(g) ? 2 : wpc1) : (g->C1 == 128) ? 2 : 1;
+  static const int wpc128 = getenv("EFFQ_I8_WPC128") ? atoi(getenv("EFFQ_I8_WPC128")) : 2;   // tuning aid
+  const int wg_per_cu = (g->C1 == 32) ? (i8_two_plane(g) ? 2 : wpc1) : (g->C1 == 128) ? wpc128 : 1;
   int gx = (256 * wg_per_cu + ny - 1) / ny;
   if (gx < 32) gx = 32;
   if (gx > p.ntiles) gx = p.ntiles;
