@@ -109,6 +109,9 @@ class OpTimer:
             self._wrap(ops, "gram_i8", lambda xi, cls, y, geom, *a, **kw: gkey(geom)),
             self._wrap(ops, "spd_inverse", lambda A0, *a, **kw: (int(A0.shape[0]),)),
             self._wrap(ops, "prox_solve", lambda B0, *a, **kw: (int(B0.shape[0]), int(B0.shape[1]))),
+            # the fused chain step (prox GEMM + scale fixed point + projection; iteration 0's shifted solve is left out)
+            self._wrap(ops, "chain_step", lambda a, *r, **kw: None if (len(r) > 9 and r[9]) or kw.get("shift_terms")
+                       else (int(a.c2), int(a.n))),
         ]
         return lambda: [u() for u in undo]
 
@@ -141,6 +144,10 @@ class OpTimer:
             n = key[1]
             return ("mfma", 2.0 * n ** 3, "f64 MFMA", PEAK_F64_MFMA_TFLOPS, "TFLOP/s", f"k_gj_* (n={n}, 2n^3 fp64 flop)")
         c2, n = key[1:]
+        if op == "chain_step":
+            return ("mfma", 2.0 * c2 * n * n, "f32 MFMA", PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
+                    f"ADMM chain step (c2={c2}, n={n}): k_build_b + k_prox_gemm (2 c2 n^2 flop, counted) + scale fixed "
+                    f"point + projection, one binding call")
         return ("mfma", 2.0 * c2 * n * n, "f32 MFMA", PEAK_F32_MFMA_TFLOPS, "TFLOP/s", f"k_prox_gemm (c2={c2}, n={n})")
 
     def summary(self):
@@ -166,9 +173,31 @@ class OpTimer:
                              launches=self.count.get(key, len(ms)), timed_launches=len(ms), avg_ms=round(avg, 4),
                              total_ms=round(avg * self.count.get(key, len(ms)), 1), work_per_launch=work,
                              overlapped=side))
+        # A loss conv runs on the loss stream under the chain step of the NEXT iteration of its layer: where the chain
+        # step is the longer of the two, the conv is hidden (its event time is mostly queueing behind the chain's
+        # kernels) and does not belong in the ranking of critical-path ops.
+        chain_avg = {}
+        for key, pairs in self.rec.items():
+            if key[0] == "chain_step":
+                ms = [a.elapsed_time(b) for a, b in pairs]
+                chain_avg[key[1:]] = sum(ms) / len(ms)
+        for key, row in zip(self.rec.keys(), rows):
+            if key[0] in ("conv_step", "conv_step_i8", "conv_step_i8s") and not row["overlapped"]:
+                N, c1, c2, D, H, W, k, st = key[1:]
+                ca = chain_avg.get((c2, c1 * k ** 3 + 1))
+                if ca is not None and row["launches"] >= 100 and row["avg_ms"] < 0.8 * ca:
+                    row["overlapped"] = True
+                    row["kernel"] += f" [loss stream, hidden under the {ca:.3f} ms chain step of its layer]"
         rows.sort(key=lambda r: (r["overlapped"], -r["total_ms"]))
         if not rows:
             return None, []
+        # `roofline` is the largest SINGLE-KERNEL op of the critical path (its duration can be checked against the
+        # rocprofv3 kernel summary); the chain steps are several kernels behind one binding call and are listed with
+        # the other ops (composite = true)
+        for r in rows:
+            r["composite"] = r["kernel"].startswith("ADMM chain step")
+        first = next((i for i, r in enumerate(rows) if not r["composite"] and not r["overlapped"]), 0)
+        rows.insert(0, rows.pop(first))
         for r in rows:
             log(f"[ops] {r['total_ms']:9.1f} ms {r['launches']:6d} x {r['avg_ms']:9.4f} ms  {r['frac']:.3f} of {r['bound']} "
                 f"peak  {r['kernel'][:90]}")
