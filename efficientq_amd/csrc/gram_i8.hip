@@ -37,6 +37,7 @@ struct GramI8Params {
   const int8_t* yd;
   const int* vox_list;
   const int* chunk_cls;   // int32 so that the (uniform) reads are scalar loads, off the vmcnt queue
+  const int* vtab;        // [nchunks*128][4] {xbase, tap mask, vout, -} per list slot, built once per launch
   int N, C1, C2, C2P, D, H, W, OD, OH, OW;
   int KD, KH, KW, SD, SH, SW, PD, PH, PW;
   int T, RX, YR0, E, NB, NBX, npairs;
@@ -56,6 +57,44 @@ __device__ __forceinline__ void gi_transpose4(int r0, int r1, int r2, int r3, in
   o[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302);
   o[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100);
   o[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302);
+}
+
+// per-voxel gather entry: input-space corner of the receptive field, validity mask of the taps (bit 31 = voxel
+// valid) and the output voxel index.  Built ONCE per launch for every list slot (k_gi_voxtable); the main kernel
+// used to rebuild it per (block pair, chunk) - three integer divisions and a 27-step mask loop on half of its waves.
+__device__ __forceinline__ gi_v4i gi_build_entry(const GramI8Params& p, int v) {
+  gi_v4i e = {0, 0, 0, 0};
+  if (v < 0) return e;
+  int t = v;
+  const int ow = t % p.OW;
+  t /= p.OW;
+  const int oh = t % p.OH;
+  t /= p.OH;
+  const int od = t % p.OD;
+  const int n = t / p.OD;
+  const int id0 = od * p.SD - p.PD, ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
+  unsigned m = 0x80000000u;
+  int tap = 0;
+  for (int kd = 0; kd < p.KD; ++kd)
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw, ++tap) {
+        const int id = id0 + kd, ih = ih0 + kh, iw = iw0 + kw;
+        const bool ok = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        m |= (ok ? 1u : 0u) << tap;
+      }
+  e[0] = ((n * p.D + id0) * p.H + ih0) * p.W + iw0;
+  e[1] = (int)m;
+  e[2] = v;
+  return e;
+}
+
+__global__ __launch_bounds__(256) void k_gi_voxtable(GramI8Params p, gi_v4i* __restrict__ table) {
+  const long long nslots = (long long)p.nchunks * GI_KC;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += stride) {
+    const int v = (p.vox_list != nullptr) ? p.vox_list[s] : ((s < p.V) ? (int)s : -1);
+    table[s] = gi_build_entry(p, v);
+  }
 }
 
 __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
@@ -110,43 +149,7 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
   const unsigned char* const srcJ = (kindJ == 1) ? reinterpret_cast<const unsigned char*>(p.yd) : p.x;
   const int ystride = 4 * p.C2P;
 
-  // voxel list entry of chunk cc for table slot k: the load is unconditional (a dummy address without a
-  // list) and its value is only looked at by list_value() after the MFMAs
-  const bool has_list = p.vox_list != nullptr;
-  auto list_load = [&](int cc, int k) -> int {
-    const long long pos = (long long)cc * GI_KC + k;
-    const int* lp = has_list ? (p.vox_list + pos) : reinterpret_cast<const int*>(p.x);
-    return *lp;
-  };
-  auto list_value = [&](int raw, int cc, int k) -> int {
-    const long long pos = (long long)cc * GI_KC + k;
-    return has_list ? raw : ((pos < p.V) ? (int)pos : -1);
-  };
-  auto build_entry = [&](int v) -> gi_v4i {
-    gi_v4i e = {0, 0, 0, 0};
-    if (v < 0) return e;
-    int t = v;
-    const int ow = t % p.OW;
-    t /= p.OW;
-    const int oh = t % p.OH;
-    t /= p.OH;
-    const int od = t % p.OD;
-    const int n = t / p.OD;
-    const int id0 = od * p.SD - p.PD, ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
-    unsigned m = 0x80000000u;
-    int tap = 0;
-    for (int kd = 0; kd < p.KD; ++kd)
-      for (int kh = 0; kh < p.KH; ++kh)
-        for (int kw = 0; kw < p.KW; ++kw, ++tap) {
-          const int id = id0 + kd, ih = ih0 + kh, iw = iw0 + kw;
-          const bool ok = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-          m |= (ok ? 1u : 0u) << tap;
-        }
-    e[0] = ((n * p.D + id0) * p.H + ih0) * p.W + iw0;
-    e[1] = (int)m;
-    e[2] = v;
-    return e;
-  };
+  const gi_v4i* const vtab = reinterpret_cast<const gi_v4i*>(p.vtab);
 
   // one unit = 4 unconditional 16-byte loads (clamped addresses); validity bits are applied when the unit is
   // staged, so nothing touches the loaded registers before the MFMAs (keeps the prefetch asynchronous)
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
   {
     const int k = tid & (GI_KC - 1);
     const int cc = (tid < GI_KC) ? c_begin : min(c_begin + 1, c_end - 1);
-    tbl[(tid < GI_KC ? 0 : 1) * GI_KC + k] = build_entry(list_value(list_load(cc, k), cc, k));
+    tbl[(tid < GI_KC ? 0 : 1) * GI_KC + k] = vtab[(size_t)cc * GI_KC + k];
   }
   __syncthreads();
   GI_FETCH(vI, okI, kindI, tapI, offI, srcI, 0)
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
     const int b = (c - c_begin) & 1;
     const int c2 = min(c + 2, c_end - 1);
     const int cls_raw = clsp[has_cls ? c2 : 0];
-    const int lraw = list_load(c2, tid & (GI_KC - 1));         // lands under the MFMAs
+    const gi_v4i traw = vtab[(size_t)c2 * GI_KC + (tid & (GI_KC - 1))];   // lands under the MFMAs
     GI_FETCH(vI, okI, kindI, tapI, offI, srcI, b ^ 1)          // chunk c+1 (its table was built last iteration)
     if (!diag) GI_FETCH(vJ, okJ, kindJ, tapJ, offJ, srcJ, b ^ 1)
     __builtin_amdgcn_sched_barrier(0);
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
       }
     }
     if (cls_next != cls_cur && live) flush(cls_cur);
-    if (tid < GI_KC) tbl[b * GI_KC + tid] = build_entry(list_value(lraw, c2, tid));   // chunk c+2 replaces chunk c
+    if (tid < GI_KC) tbl[b * GI_KC + tid] = traw;              // table of chunk c+2 replaces chunk c's
     if (p.debug != 3) {
       stage(panI + (b ^ 1) * GI_PANEL, vI, okI, kindI);
       if (!diag) stage(panJ + (b ^ 1) * GI_PANEL, vJ, okJ, kindJ);
@@ -411,6 +414,9 @@ static int gram_i8_plan(const effq_geom* g, int ncls, long long n_list, GramI8Pa
   return EFFQ_OK;
 }
 
+// upper bound of the list length: every class run is padded to a multiple of 128 slots
+static size_t gram_i8_table_bytes(long long V, int ncls) { return (size_t)(V + (long long)GI_KC * (ncls + 1)) * 16; }
+
 static size_t gram_i8_slab_bytes(const GramI8Params& p) {
   return (size_t)p.ncls * p.npairs * (size_t)(GI_MB * GI_MB) * sizeof(long long);
 }
@@ -433,7 +439,7 @@ int effq_gram_i8_supported(const effq_geom* g, int act_levels) {
 size_t effq_gram_i8_ws_bytes(const effq_geom* g, int ncls) {
   GramI8Params p;
   if (gram_i8_plan(g, ncls, 0, &p) != EFFQ_OK) return 0;
-  return 256 + gram_i8_slab_bytes(p) + (size_t)p.V * 4 * p.C2P + 256;
+  return 256 + gram_i8_slab_bytes(p) + (size_t)p.V * 4 * p.C2P + 256 + gram_i8_table_bytes(p.V, ncls) + 256;
 }
 
 int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const effq_geom* g, int has_bias,
@@ -451,7 +457,8 @@ int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const ef
   int rc = gram_i8_plan(g, ncls, n_list, &p);
   if (rc != EFFQ_OK) return rc;
   const size_t slab_bytes = gram_i8_slab_bytes(p);
-  const size_t need = 256 + slab_bytes + (size_t)p.V * 4 * p.C2P + 256;
+  const size_t need = 256 + slab_bytes + (size_t)p.V * 4 * p.C2P + 256 + gram_i8_table_bytes(p.V, ncls) + 256;
+  EFFQ_CHECK_ARG((size_t)p.nchunks * GI_KC * 16 <= gram_i8_table_bytes(p.V, ncls));
   if (ws_bytes < need) {
     set_error("gram_i8: workspace %zu < required %zu", ws_bytes, need);
     return EFFQ_ERR_WORKSPACE;
@@ -460,10 +467,12 @@ int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const ef
   unsigned* ymax = reinterpret_cast<unsigned*>(base);
   p.slabs = reinterpret_cast<long long*>(base + 256);
   int8_t* yd = reinterpret_cast<int8_t*>(base + 256 + slab_bytes);
+  gi_v4i* vtab = reinterpret_cast<gi_v4i*>((reinterpret_cast<uintptr_t>(base + 256 + slab_bytes + (size_t)p.V * 4 * p.C2P) + 255) & ~(uintptr_t)255);
   p.x = xidx_ndhwc;
   p.yd = yd;
   p.vox_list = vox_list;
   p.chunk_cls = chunk_cls;
+  p.vtab = reinterpret_cast<const int*>(vtab);
   {
     const char* dbg = getenv("EFFQ_GI8_DEBUG");
     p.debug = dbg ? atoi(dbg) : 0;
@@ -478,6 +487,12 @@ int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const ef
     size_t nd = ((size_t)p.V * p.C2P + 255) / 256;
     if (nd > 8192) nd = 8192;
     hipLaunchKernelGGL(k_gi_ydigits, dim3((unsigned)nd), dim3(256), 0, st, y_ndhwc, p.V, p.C2, p.C2P, ymax, yd);
+    EFFQ_LAUNCH_CHECK();
+  }
+  {
+    size_t nt = ((size_t)p.nchunks * GI_KC + 255) / 256;
+    if (nt > 4096) nt = 4096;
+    hipLaunchKernelGGL(k_gi_voxtable, dim3((unsigned)nt), dim3(256), 0, st, p, vtab);
     EFFQ_LAUNCH_CHECK();
   }
   static bool attr_set = false;
