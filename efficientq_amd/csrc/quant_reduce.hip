@@ -453,6 +453,16 @@ __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, cons
     st->iters = it;
     st->done = done;
   }
+  // leave the barrier counter at zero for the next launch: every workgroup is past its last poll when it gets
+  // here, so the last one to check out (counter[1]) resets both words - no memset command per call.  (After a
+  // barrier time-out the early returns above skip this; the host then sees done = 3 and raises.)
+  if (tid == 0) {
+    const unsigned left = __hip_atomic_fetch_add(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == (unsigned)G - 1) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 __global__ void k_check_state(const effq_fp_state* st, int32_t* err_flag) {
@@ -748,11 +758,14 @@ static int fixed_point_coop_impl(const float* a, const float* b, float* v_out, s
   EFFQ_CHECK_ARG(G <= FPC_MAXG);
   const size_t per = (n + G - 1) / G;
   const size_t lds = per * sizeof(float);
-  // workspace: reuse the reduction workspace: partials [2][FPC_MAXG][2] doubles at its start, counter after them
+  // workspace: reuse the reduction workspace: partials [2][FPC_MAXG][2] doubles at its start
   double* partials = reinterpret_cast<double*>(ws);
-  unsigned int* counter = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(ws) + 2 * FPC_MAXG * 2 * sizeof(double));
+  // the two counter words sit in the tail of the reduction workspace (after the ticket), where no reduction kernel
+  // writes partial sums: they must still be zero from the previous launch
+  unsigned int* counter = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(ws) +
+                                                          sizeof(double) * RED_MAX_BLOCKS * RED_SLOTS + 64);
   hipStream_t st = as_stream(stream);
-  EFFQ_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), st));
+  // (the kernel leaves its two counter words at zero; the reduction workspace is zero-filled at creation)
   static bool attr_set = false;
   if (!attr_set) {
     EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fp_coop<FPC_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
