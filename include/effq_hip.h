@@ -111,7 +111,8 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
 /* Same contract for larger tensors (n <= effq_fp_coop_max()): one COOPERATIVE launch of ceil(n/27648) <= 256
  * workgroups (one per CU, slice of v resident in LDS) that meet at a bounded-spin grid barrier once per
  * iteration; partial sums are combined in workgroup order by every workgroup (deterministic).  state.done = 3
- * reports a barrier time-out.  ws: the reduction workspace (effq_reduce_ws_bytes()). */
+ * reports a barrier time-out.  ws: the reduction workspace (effq_reduce_ws_bytes()), zero-filled once by the caller:
+ * the kernel keeps its barrier words in the tail of it and leaves them at zero. */
 size_t effq_fp_coop_max(void);
 int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                           double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream);
