@@ -72,6 +72,8 @@ class HipOps:
         self._ws = {}
         self._att_cache = {}
         self._pinned_stream = None
+        self._pinned_torch = None
+        self._ws_retired = []
 
     # -- plumbing ---------------------------------------------------------------------------
     @property
@@ -85,12 +87,13 @@ class HipOps:
     def on_stream(self, stream: Optional["torch.cuda.Stream"]):
         """Pin the HIP stream the following ops launch on (None: follow torch's current stream again).
         Returns the previous pin so that callers can restore it."""
-        prev = self._pinned_stream
+        prev = (self._pinned_stream, self._pinned_torch)
         self._pinned_stream = None if stream is None else C.c_void_p(stream.cuda_stream)
+        self._pinned_torch = stream
         return prev
 
     def restore_stream(self, pin):
-        self._pinned_stream = pin
+        self._pinned_stream, self._pinned_torch = pin if pin is not None else (None, None)
 
     def loss_stream(self):
         """The stream the per-iteration loss evaluation runs on, one iteration behind the ADMM chain."""
@@ -105,11 +108,30 @@ class HipOps:
         return self._side
 
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        """Library workspace `key`, zero-filled when (re)allocated.  The fill is issued on the stream the NEXT op
+        launches on (the pinned stream when one is set): a fill on torch's current stream would race with kernels
+        of a pinned loss stream that only waited for an event recorded before the fill.  A replaced buffer stays
+        referenced until release_retired() (kernels of another stream may still be reading it, and the caching
+        allocator only orders a block against the stream it was allocated on)."""
         cur = self._ws.get(key)
         if cur is None or cur.numel() < nbytes:
-            cur = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
+            if cur is not None:
+                self._ws_retired.append(cur)
+            if self._pinned_torch is not None:
+                with torch.cuda.stream(self._pinned_torch):
+                    cur = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
+            else:
+                cur = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
             self._ws[key] = cur
         return cur
+
+    def reserve(self, key: str, nbytes: int):
+        """Size workspace `key` ahead of a multi-stream section (on the current stream, before its events)."""
+        self._workspace(key, nbytes)
+
+    def release_retired(self):
+        """Drop replaced workspaces; call only where every stream of this handle has been joined."""
+        self._ws_retired.clear()
 
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
         if t.device != self.device and not (t.device.type == "cuda" and self.device.index in (None, t.device.index)):

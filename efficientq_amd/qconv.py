@@ -424,6 +424,8 @@ class EfficientQConvHIP(PTQConv):
         if loss_s is not None:
             torch.cuda.current_stream(dev).wait_stream(loss_s)
         a_w, _, _ = ops.read_fp_state(stb[(self.lwq_iter - 1) & 1])        # one sync per layer
+        if hasattr(ops, "release_retired"):
+            ops.release_retired()        # every stream was joined and the host has synchronised
         t_loop = _time.perf_counter() - t_loop0
         if fp_err.item() != 0:                                             # layer_helper.py:62-64
             raise RuntimeWarning(f'Exceed maximum iteration ({100 * self.qlvl_w}) for alpha optimization')

@@ -237,6 +237,49 @@ def g5():
     save("g5_layer_ptq.npz", **out)
 
 
+def g5b():
+    """Reference self-spread at the dominant widths: the SAME 32->32 (and 64->64) 3^3 layer calibrated by the
+    reference with 1 and with 8 BLAS threads.  The two runs differ only in the summation order
+    inside the library GEMM / conv kernels; whatever distance separates them is the reference's own reproducibility
+    floor for this layer shape, and the bar of the product tests is anchored on it."""
+    out = {}
+    for tag, kw in {
+        "c32": dict(c1=32, c2=32, k=3, stride=1, pad=1, N=2, S=12, L_w=4, L_a=4, q_act=True, seed=2024,
+                    with_mask=True),
+        "c64": dict(c1=64, c2=64, k=3, stride=1, pad=1, N=2, S=8, L_w=4, L_a=4, q_act=True, seed=2025,
+                    with_mask=True),
+    }.items():
+        recs = {}
+        for nt in (1, 8):
+            torch.set_num_threads(nt)
+            recs[nt] = run_layer(**kw)
+        torch.set_num_threads(8)
+        base = recs[8]
+        for k in ("x", "y", "w_in", "b_in", "mask_full", "meta", "stride"):
+            out[f"{tag}_{k}"] = base[k]
+        out[f"{tag}_mask_full"] = base["mask_full"].to(torch.uint8)
+        for nt, rec in recs.items():
+            assert torch.equal(rec["x"], base["x"]) and torch.equal(rec["y"], base["y"])
+            for k in ("loss_hist", "final_mse", "aw_hist", "weight", "bias", "alpha_w", "alpha_act", "layer_loss",
+                      "fwd_q"):
+                out[f"{tag}_t{nt}_{k}"] = rec[k]
+        a, b = recs[1], recs[8]
+        L = kw["L_w"]
+        lv = lambda t: torch.round((t / t.abs().max() + 1) * (L - 1) / 2)
+        spread = dict(
+            layer_loss=abs(a["layer_loss"] - b["layer_loss"]) / b["layer_loss"],
+            best_mse=abs(a["loss_hist"].min() - b["loss_hist"].min()) / b["loss_hist"].min(),
+            idx_mismatch=(lv(a["weight"]) != lv(b["weight"])).float().mean().item(),
+            out_rel_mse=(((a["fwd_q"] - b["fwd_q"]) ** 2).mean() / (b["fwd_q"] ** 2).mean()).item(),
+            hist_first5=float(np.max(np.abs(a["loss_hist"][:5] - b["loss_hist"][:5]) / b["loss_hist"][:5])),
+            hist_max=float(np.max(np.abs(a["loss_hist"] - b["loss_hist"]) / b["loss_hist"])))
+        for k, v in spread.items():
+            out[f"{tag}_spread_{k}"] = np.float64(v)
+        print(tag, {k: f"{v:.3e}" for k, v in spread.items()}, "layer_loss t1/t8", a["layer_loss"], b["layer_loss"],
+              "best it", int(np.argmin(a["loss_hist"])), int(np.argmin(b["loss_hist"])))
+    save("g5b_wide_layers.npz", **out)
+
+
 # ---------------------------------------------------------------- G6 whole do_ptq
 def tiny_args(task, L, S, nmod, ncls, multi_label=None, init_stride="1", width="8,16,8",
               depth="1,1,1", root="/tmp/effq_gold"):
@@ -490,6 +533,8 @@ if __name__ == "__main__":
             g11()
     if "g5" in which:
         g5()
+    if "g5b" in which:
+        g5b()
     if "g6" in which:
         g6("lits", 4, 32, "g6_tiny_lits_L4")
     if "g6b" in which:

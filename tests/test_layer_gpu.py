@@ -51,41 +51,51 @@ def test_layer_calibration_matches_reference(gold, tag):
     assert abs(tr["best_mse"] - float(g[f"{tag}_loss_hist"].min())) <= 1e-3 * float(g[f"{tag}_loss_hist"].min())
 
 
-def test_layer_calibration_vs_oracle_bigger_layer():
-    """A 32->32 3^3 layer (the dominant BraTS shape, reduced volume) against the CPU oracle."""
-    from efficientq_amd.qconv import EfficientQConvHIP
-    gen = torch.Generator().manual_seed(2024)
-    c, S, N = 32, 12, 2
-    conv = EfficientQConvHIP(c, c, 3, 1, 1, 1, 1, True, q_weight=True, qlvl=4, q_act=True, qlvl_act=4)
-    with torch.no_grad():
-        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (c * 27)) ** 0.5)
-        conv.bias.copy_(torch.randn(c, generator=gen) * 0.1)
-    x_fp = torch.relu(torch.randn(N, c, S, S, S, generator=gen))
-    y = torch.nn.functional.conv3d(x_fp, conv.weight.data, conv.bias.data, 1, 1)
-    x = torch.relu(x_fp + 0.05 * torch.randn(x_fp.shape, generator=gen))
-    att = torch.randint(1, 3, (N, S, S, S), generator=gen).float()
-    want = O.calibrate_layer(x, y, conv.weight.data.clone(), conv.bias.data.clone(), 1, 1, qlvl_w=4, qlvl_act=4,
-                             q_act=True, mask_pyramid=[att])
-    conv.output_fp, conv.name, conv.layer_loss, conv.mask_pyramid = y, "big", [], [att]
+def _rel_mse(a, b):
+    return (((a - b) ** 2).mean() / (b ** 2).mean()).item()
+
+
+@pytest.mark.parametrize("tag", ["c32", "c64"])
+def test_wide_layer_calibration_within_reference_self_spread(gold, tag):
+    """The dominant BraTS shape (32->32 3^3) and a 64->64 layer against the REFERENCE run twice on the same
+    inputs - with 1 and with 8 BLAS threads (tests/golden/make_goldens.py:g5b).  The two reference runs sit
+    S_out ~ 3e-2 output rel-MSE, S_idx ~ 5-22 % weight indices and S_ll ~ 9e-4 layer_loss apart: on these layers
+    the discrete ADMM trajectory amplifies last-ulp differences of the Gram sums, so north_star's 1e-3 output
+    bar is met by the reference against itself only on small layers (G5).  Bars here: north_star's 1e-3, or a
+    small multiple of the reference's own spread where that is larger; what precedes the divergence (scales,
+    rho_scale, the first iterations) is held to the tight bar."""
+    g = gold("g5b_wide_layers.npz")
+    conv, x, (L_w, L_a, q_act) = _layer_from_gold(g, tag)
+    conv.mask_pyramid[1] = conv.mask_pyramid[1].float()
     conv.lwq_trace = True
     _to_dev(conv)
     conv.set_quantizing()
     with torch.no_grad():
-        conv(x.to(DEV))
+        out = conv(x.to(DEV)).cpu()
+    sp = {k: float(g[f"{tag}_spread_{k}"]) for k in ("layer_loss", "best_mse", "idx_mismatch", "out_rel_mse",
+                                                      "hist_first5")}
     got_loss = float(conv.layer_loss[0].split(":")[1])
-    hist, ref_hist = np.array(conv.last_trace["loss_history"]), np.array(want.loss_history)
-    # before the discrete trajectories can separate, the per-iteration losses agree closely
-    assert np.all(np.abs(hist[:5] - ref_hist[:5]) <= 1e-4 * ref_hist[:5]), (hist[:8], ref_hist[:8])
-    # plateau value: the two runs settle on iterates whose losses agree to a fraction of a percent
-    assert abs(hist.min() - ref_hist.min()) <= 5e-3 * ref_hist.min()
-    assert abs(got_loss - want.layer_loss) <= 5e-3 * want.layer_loss
-    # NOTE: at this size the 4-level optimum is not unique: the two runs keep different iterates of the same
-    # loss plateau, so output-vs-output distance is not a parity measure here (both sit ~16% from the FP
-    # target, ~3% from each other); the quantisation error itself (layer_loss) is what must agree.
-    print(f"layer_loss hip={got_loss:.8f} oracle={want.layer_loss:.8f} best hip={hist.min():.8f} "
-          f"oracle={ref_hist.min():.8f} first-iters rel={np.abs(hist[:5] - ref_hist[:5]) / ref_hist[:5]}")
-    assert abs(conv.alpha_act.item() - np.float32(want.alpha_act)) <= 1e-6 * want.alpha_act
-    assert abs(conv.last_trace["rho_scale"] - want.rho_scale) <= 1e-6 * want.rho_scale
+    hist = np.array(conv.last_trace["loss_history"])
+    lv = lambda t: torch.round((t / t.abs().max() + 1) * (L_w - 1) / 2)
+    w = conv.weight.data.cpu()
+    rep = {}
+    for nt in (1, 8):
+        ref_hist = g[f"{tag}_t{nt}_loss_hist"]
+        a_ref = float(g[f"{tag}_t{nt}_alpha_act"])
+        assert abs(conv.alpha_act.item() - a_ref) <= 1e-6 * a_ref
+        # before the discrete trajectories separate: north_star's bar / 10, or 3x what the reference shows itself
+        bar5 = max(1e-4, 3 * sp["hist_first5"])
+        assert np.all(np.abs(hist[:5] - ref_hist[:5]) <= bar5 * ref_hist[:5]), (hist[:5], ref_hist[:5])
+        d_ll = abs(got_loss - float(g[f"{tag}_t{nt}_layer_loss"])) / float(g[f"{tag}_t{nt}_layer_loss"])
+        d_best = abs(hist.min() - ref_hist.min()) / ref_hist.min()
+        d_idx = (lv(w) != lv(T(g[f"{tag}_t{nt}_weight"]))).float().mean().item()
+        d_out = _rel_mse(out, T(g[f"{tag}_t{nt}_fwd_q"]))
+        rep[nt] = (d_ll, d_best, d_idx, d_out)
+        assert d_ll <= max(1e-3, 3 * sp["layer_loss"]), (d_ll, sp)
+        assert d_best <= max(1e-3, 3 * sp["best_mse"]), (d_best, sp)
+        assert d_idx <= 2 * sp["idx_mismatch"], (d_idx, sp)
+        assert d_out <= max(1e-3, 2 * sp["out_rel_mse"]), (d_out, sp)      # the assertion r1 had dropped
+    print(f"{tag}: reference self-spread {sp}; hip vs t1/t8 (layer_loss, best, idx, out rel-MSE) = {rep}")
 
 
 @pytest.mark.parametrize("task,fname", [("brats", "g6_tiny_brats_L4.npz"), ("lits", "g6_tiny_lits_L4.npz")])
@@ -123,6 +133,40 @@ def test_whole_calibration_matches_reference(gold, task, fname):
     agree = ((res["output_q"][-1] > 0) == (res["output_fp"][-1] > 0)).float().mean().item()
     assert abs(agree - float(g["agree"])) <= 1e-2       # Dice-proxy within 1 pt on the tiny net
     assert res["t2"] > res["t1"] > res["t0"]
+
+
+def test_workspace_growth_inside_the_overlapped_loop_is_ordered_on_the_loss_stream():
+    """a loss-stream workspace that grows mid-layer used to be zero-filled on torch's current
+    stream, unordered against the pinned loss stream.  Drop the integer-conv workspaces so that they grow inside
+    the loop, once with the two-stream overlap and once serial: the per-iteration losses (exact integer sums,
+    deterministic) must be identical."""
+    from efficientq_amd.qconv import EfficientQConvHIP, get_ops
+    cases = {"i8 32->32": dict(c1=32, c2=32, k=3, s=1, p=1, S=40, N=2, L=4),
+             "i8s 4->32 s2, 256 levels": dict(c1=4, c2=32, k=3, s=2, p=1, S=64, N=4, L=256)}
+    for name, c in cases.items():
+        hist = {}
+        for overlap in (True, False):
+            gen = torch.Generator().manual_seed(5)
+            conv = EfficientQConvHIP(c["c1"], c["c2"], c["k"], c["s"], c["p"], 1, 1, True, q_weight=True,
+                                     qlvl=c["L"], q_act=True, qlvl_act=c["L"], lwq_trace=True,
+                                     lwq_overlap_loss=overlap)
+            with torch.no_grad():
+                conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (c["c1"] * 27)) ** 0.5)
+                conv.bias.copy_(torch.randn(c["c2"], generator=gen) * 0.1)
+            x = torch.relu(torch.randn(c["N"], c["c1"], c["S"], c["S"], c["S"], generator=gen))
+            y = torch.nn.functional.conv3d(x, conv.weight.data, conv.bias.data, c["s"], c["p"])
+            conv.output_fp, conv.name, conv.layer_loss = y, "ws", []
+            _to_dev(conv)
+            ops = get_ops(torch.device(DEV))
+            torch.cuda.synchronize()
+            for key in ("conv_i8", "conv_i8s"):
+                ops._ws.pop(key, None)
+            conv.set_quantizing()
+            with torch.no_grad():
+                conv(x.to(DEV))
+            assert conv.last_trace["exact_int"], name
+            hist[overlap] = np.array(conv.last_trace["loss_history"])
+        assert np.array_equal(hist[True], hist[False]), (name, np.abs(hist[True] - hist[False]).max())
 
 
 def test_exact_int_and_fp32_loss_paths_agree_on_a_layer():
