@@ -58,6 +58,27 @@ class ChainArgs(C.Structure):
                 ("levels", C.c_int32), ("shift_terms", C.c_int32), ("max_iter", C.c_int32), ("rho", C.c_double),
                 ("eta", C.c_double), ("rho_inv", C.c_double), ("tol", C.c_double), ("dual_div", C.c_float)]
 
+class AdmmRunArgs(C.Structure):
+    """effq_admm_run_args of include/effq_hip.h."""
+    _fields_ = [("A0", C.c_void_p), ("B0", C.c_void_p), ("W0", C.c_void_p), ("b0", C.c_void_p),
+                ("c2", C.c_int32), ("n", C.c_int32), ("has_bias", C.c_int32), ("w_levels", C.c_int32),
+                ("iters", C.c_int32), ("rho_period", C.c_int32),
+                ("rho", C.c_double), ("rho_max", C.c_double), ("eta", C.c_double), ("tol", C.c_double),
+                ("geom", Geom), ("loss_kind", C.c_int32), ("act_levels", C.c_int32),
+                ("xq", C.c_void_p), ("xidx", C.c_void_p), ("y_fp", C.c_void_p), ("act_alpha_dev", C.c_void_p),
+                ("dual", C.c_void_p), ("wstar", C.c_void_p), ("v", C.c_void_p),
+                ("G_ring", C.c_void_p), ("Gq_ring", C.c_void_p), ("b_ring", C.c_void_p), ("state_ring", C.c_void_p),
+                ("hist", C.c_void_p), ("err_flag", C.c_void_p),
+                ("ainv_pool", C.c_void_p), ("n_ainv", C.c_int32),
+                ("prox_ws", C.c_void_p), ("prox_ws_bytes", C.c_size_t),
+                ("red_ws", C.c_void_p),
+                ("fp_ws", C.c_void_p), ("fp_ws_bytes", C.c_size_t),
+                ("inv_ws", C.c_void_p), ("inv_ws_bytes", C.c_size_t),
+                ("inv_ws_side", C.c_void_p), ("inv_ws_side_bytes", C.c_size_t),
+                ("conv_ws", C.c_void_p), ("conv_ws_bytes", C.c_size_t),
+                ("stream_main", C.c_void_p), ("stream_loss", C.c_void_p), ("stream_side", C.c_void_p)]
+
+
 # name -> (restype, argtypes).  Must list every symbol include/effq_hip.h declares.
 SIGNATURES = {
     "effq_last_error": (C.c_char_p, []),
@@ -76,7 +97,13 @@ SIGNATURES = {
     "effq_fixed_point_small": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P]),
     "effq_fp_coop_max": (_SZ, []),
     "effq_fixed_point_coop": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _P]),
+    "effq_fp_bucket_max": (_SZ, []),
+    "effq_fp_bucket_ws_bytes": (_SZ, [_SZ]),
+    "effq_fixed_point_bucket": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _SZ, _P]),
     "effq_fp_check": (_I, [_P, _P, _P]),
+    "effq_admm_num_inverses": (_I, [_D, _D, _I, _I]),
+    "effq_admm_run": (_I, [C.POINTER(AdmmRunArgs)]),
+    "effq_admm_select_best": (_I, [_P, _I, _P, _P, _SZ, _SZ, _P, _P, _P, _P]),
     "effq_gram_ws_bytes": (_SZ, [_GP, _I]),
     "effq_gram_accum": (_I, [_P, _P, _P, _GP, _I, _P, _P, _I, _P, _SZ, _P]),
     "effq_gram_i8_supported": (_I, [_GP, _I]),

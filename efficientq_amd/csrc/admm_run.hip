@@ -1,0 +1,284 @@
+// The whole ADMM loop of one layer (EfficientQConv.py:99-144) enqueued by ONE C call.
+//
+// The loop body is launch-bound for most layers of a network (a few tens of microseconds of GPU work per iteration),
+// so issuing it from the host language costs more than running it.  effq_admm_run() enqueues all iterations on up to
+// three caller-owned HIP streams:
+//   main : prox solve -> scale fixed point -> projection + dual update            (the serial chain)
+//   loss : conv + squared error of iteration i, while main computes i+1            (best-iterate selection only)
+//   side : the inverses of A(rho) for the later rho values, under the iterations that precede their first use
+// Every per-iteration result the loss stream reads lives in a RING indexed by the iteration (G, its int8 operands,
+// b*, the scale state): slots are written once, so main never waits for loss.  The squared errors land in hist[i];
+// the best iterate is picked AFTER the loop (effq_admm_select_best), which is what lets a data-parallel caller
+// all-reduce the whole history with one collective per layer instead of one per iteration.
+#include <vector>
+#include "common.h"
+
+extern "C" {
+int effq_project_dual_checked(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
+                              float* dual, float dual_div, int8_t* Gq_out, size_t n, int32_t* err_flag_dev,
+                              void* stream);   // quant_reduce.hip (internal)
+}
+
+namespace effq {
+
+constexpr int ADMM_MAX_RHOS = 16;
+
+struct RhoPlan {
+  int count;                       // distinct rho values, in order of first use
+  double rho[ADMM_MAX_RHOS];
+  int first_iter[ADMM_MAX_RHOS];   // iteration of first use
+  bool shifted_first;              // rho[0] serves iteration 0 only: solved through the inverse of A(rho[1])
+  bool overflow;
+};
+
+// EfficientQConv.py:129-137: at i % period == 0 (after the iteration), rho doubles while 2*rho <= rho_max, else -> rho_max
+static RhoPlan plan_rhos(double rho, double rho_max, int iters, int period) {
+  RhoPlan p;
+  p.count = 0;
+  p.overflow = false;
+  double r = rho;
+  for (int i = 0; i < iters; ++i) {
+    if (p.count == 0 || p.rho[p.count - 1] != r) {
+      if (p.count == ADMM_MAX_RHOS) {
+        p.overflow = true;
+        break;
+      }
+      p.rho[p.count] = r;
+      p.first_iter[p.count] = i;
+      ++p.count;
+    }
+    if (i % period == 0) r = (r * 2 <= rho_max) ? r * 2 : rho_max;
+  }
+  p.shifted_first = p.count > 1 && p.first_iter[1] == 1 && p.rho[1] > p.rho[0];
+  return p;
+}
+
+static int shift_terms(double rho, double eta, double rho_inv) {
+  // sweeps of the contraction (factor d / (rho_inv + eta)) to reach 2^-26
+  const double d = rho_inv - rho;
+  if (d <= 0) return 1;
+  int t = (int)ceil(-26.0 * log(2.0) / log(d / (rho_inv + eta)));
+  return t < 2 ? 2 : (t > 64 ? 64 : t);
+}
+
+__global__ __launch_bounds__(256) void k_select_best(const double* __restrict__ hist, int iters,
+                                                     const float* __restrict__ G_ring, const float* __restrict__ b_ring,
+                                                     size_t nw, size_t nb, float* __restrict__ best_G,
+                                                     float* __restrict__ best_b, double* __restrict__ best_out) {
+  // "if i == 0 or lossf < best" (EfficientQConv.py:139-142): the EARLIEST minimum; every thread scans the same doubles
+  int bi = 0;
+  double bl = hist[0];
+  for (int i = 1; i < iters; ++i) {
+    const double l = hist[2 * (size_t)i];
+    if (l < bl) {
+      bl = l;
+      bi = i;
+    }
+  }
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float* g = G_ring + (size_t)bi * nw;
+  for (size_t i = t0; i < nw; i += stride) best_G[i] = g[i];
+  if (b_ring != nullptr)
+    for (size_t i = t0; i < nb; i += stride) best_b[i] = b_ring[(size_t)bi * nb + i];
+  if (t0 == 0) {
+    best_out[0] = bl;
+    best_out[1] = (double)bi;
+  }
+}
+
+}  // namespace effq
+using namespace effq;
+
+extern "C" {
+
+int effq_admm_num_inverses(double rho, double rho_max, int iters, int period) {
+  if (!(rho > 0.0) || iters <= 0 || period <= 0) return -1;
+  const RhoPlan p = plan_rhos(rho, rho_max, iters, period);
+  if (p.overflow) return -1;
+  return p.count - (p.shifted_first ? 1 : 0);
+}
+
+int effq_admm_run(const effq_admm_run_args* a) {
+  EFFQ_CHECK_ARG(a != nullptr);
+  EFFQ_CHECK_ARG(a->A0 && a->B0 && a->W0 && a->dual && a->wstar && a->v && a->G_ring && a->state_ring && a->hist &&
+                 a->err_flag && a->ainv_pool && a->prox_ws && a->red_ws && a->inv_ws && a->conv_ws && a->y_fp);
+  EFFQ_CHECK_ARG(a->c2 > 0 && a->n > 1 && a->iters > 0 && a->rho_period > 0 && a->w_levels >= 2 && a->w_levels <= 256);
+  EFFQ_CHECK_ARG((a->has_bias != 0) == (a->b0 != nullptr) && (a->has_bias != 0) == (a->b_ring != nullptr));
+  EFFQ_CHECK_ARG(a->loss_kind >= 0 && a->loss_kind <= 2);
+  EFFQ_CHECK_ARG(a->loss_kind == 0 ? (a->xq != nullptr) : (a->xidx != nullptr && a->Gq_ring != nullptr &&
+                                                          a->act_alpha_dev != nullptr));
+  const int c2 = a->c2, n = a->n, has_b = a->has_bias ? 1 : 0;
+  const size_t nw = (size_t)c2 * (size_t)(n - has_b);
+  EFFQ_CHECK_ARG(nw == (size_t)a->geom.C2 * a->geom.C1 * a->geom.KD * a->geom.KH * a->geom.KW);
+  if (nw > effq_fp_coop_max()) {
+    set_error("admm_run: %zu weights exceed the single-launch fixed points", nw);
+    return EFFQ_ERR_ARG;
+  }
+  const bool bucket = nw <= effq_fp_bucket_max() && a->fp_ws != nullptr;
+  if (bucket && a->fp_ws_bytes < effq_fp_bucket_ws_bytes(nw)) {
+    set_error("admm_run: fixed-point workspace %zu < %zu", a->fp_ws_bytes, effq_fp_bucket_ws_bytes(nw));
+    return EFFQ_ERR_WORKSPACE;
+  }
+  const RhoPlan plan = plan_rhos(a->rho, a->rho_max, a->iters, a->rho_period);
+  EFFQ_CHECK_ARG(!plan.overflow);
+  const int first = plan.shifted_first ? 1 : 0;
+  const int n_inv = plan.count - first;
+  EFFQ_CHECK_ARG(a->n_ainv >= n_inv);
+  const size_t ainv_elems = (size_t)n * (size_t)effq_ainv_ld(n);
+
+  hipStream_t s_main = as_stream(a->stream_main);
+  hipStream_t s_loss = a->stream_loss ? as_stream(a->stream_loss) : s_main;
+  hipStream_t s_side = (a->stream_side && a->inv_ws_side) ? as_stream(a->stream_side) : s_main;
+  const bool fork_loss = s_loss != s_main, fork_side = s_side != s_main;
+
+  // events: one per inverse formed on the side stream, a small pool for main -> loss, one each for the joins.  They
+  // come from a per-thread, per-device pool that is never destroyed (a wait captures the record that precedes it, so
+  // an event may be re-recorded by the next call while an older wait on it is still queued).
+  constexpr int EV_POOL = 4;
+  int dev_id = 0;
+  EFFQ_HIP(hipGetDevice(&dev_id));
+  static thread_local std::vector<std::vector<hipEvent_t>> g_events;
+  if ((int)g_events.size() <= dev_id) g_events.resize(dev_id + 1);
+  std::vector<hipEvent_t>& pool = g_events[dev_id];
+  size_t pool_used = 0;
+  auto new_event = [&](hipEvent_t* e) -> hipError_t {
+    if (pool_used == pool.size()) {
+      hipEvent_t fresh;
+      hipError_t rc = hipEventCreateWithFlags(&fresh, hipEventDisableTiming);
+      if (rc != hipSuccess) return rc;
+      pool.push_back(fresh);
+    }
+    *e = pool[pool_used++];
+    return hipSuccess;
+  };
+  auto destroy_events = [&]() {};
+#define ADMM_HIP(call)                                                                        \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      effq::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));     \
+      destroy_events();                                                                       \
+      return EFFQ_ERR_HIP;                                                                    \
+    }                                                                                         \
+  } while (0)
+#define ADMM_RC(call)          \
+  do {                         \
+    int rc_ = (call);          \
+    if (rc_ != EFFQ_OK) {      \
+      destroy_events();        \
+      return rc_;              \
+    }                          \
+  } while (0)
+
+  hipEvent_t ev_inv[ADMM_MAX_RHOS] = {};
+  hipEvent_t ev_main[EV_POOL] = {};
+  hipEvent_t ev_fork = nullptr, ev_join_loss = nullptr, ev_join_side = nullptr;
+
+  ADMM_HIP(hipMemsetAsync(a->dual, 0, nw * sizeof(float), s_main));                 // dual <- 0 (EfficientQConv.py:40)
+  // the inverse the first iterations need, on the main stream; the later ones on the side stream
+  ADMM_RC(effq_spd_inverse(a->A0, n, has_b, plan.rho[first], a->eta, a->ainv_pool, a->inv_ws, a->inv_ws_bytes, s_main));
+  if (n_inv > 1) {
+    if (fork_side) {
+      ADMM_HIP(new_event(&ev_fork));
+      ADMM_HIP(hipEventRecord(ev_fork, s_main));       // A0 (and everything before the call) is ready
+      ADMM_HIP(hipStreamWaitEvent(s_side, ev_fork, 0));
+    }
+    for (int r = first + 1; r < plan.count; ++r) {
+      float* dst = a->ainv_pool + (size_t)(r - first) * ainv_elems;
+      void* ws = fork_side ? a->inv_ws_side : a->inv_ws;
+      const size_t wsb = fork_side ? a->inv_ws_side_bytes : a->inv_ws_bytes;
+      ADMM_RC(effq_spd_inverse(a->A0, n, has_b, plan.rho[r], a->eta, dst, ws, wsb, s_side));
+      if (fork_side) {
+        ADMM_HIP(new_event(&ev_inv[r]));
+        ADMM_HIP(hipEventRecord(ev_inv[r], s_side));
+      }
+    }
+  }
+  if (fork_loss)
+    for (int e = 0; e < EV_POOL; ++e) ADMM_HIP(new_event(&ev_main[e]));
+
+  double rho = a->rho;
+  int cur = -1;     // index into plan.rho of the inverse in use
+  const float* Ainv = nullptr;
+  for (int i = 0; i < a->iters; ++i) {
+    const bool use_shift = plan.shifted_first && i == 0;
+    if (!use_shift && (cur < 0 || plan.rho[cur] != rho)) {
+      int r = first;
+      while (r < plan.count && plan.rho[r] != rho) ++r;
+      EFFQ_CHECK_ARG(r < plan.count);
+      if (fork_side && ev_inv[r] != nullptr) ADMM_HIP(hipStreamWaitEvent(s_main, ev_inv[r], 0));
+      Ainv = a->ainv_pool + (size_t)(r - first) * ainv_elems;
+      cur = r;
+    }
+    float dual_div = 1.0f;
+    if (i % a->rho_period == 0) dual_div = (rho * 2 <= a->rho_max) ? 2.0f : (float)(a->rho_max / rho);
+    const float* G_prev = (i == 0) ? a->W0 : a->G_ring + (size_t)(i - 1) * nw;
+    float* G = a->G_ring + (size_t)i * nw;
+    int8_t* Gq = a->Gq_ring ? a->Gq_ring + (size_t)i * nw : nullptr;
+    float* bstar = has_b ? a->b_ring + (size_t)i * c2 : nullptr;
+    effq_fp_state* st = a->state_ring + i;
+    // ---- the chain (main stream) ----
+    if (use_shift)
+      ADMM_RC(effq_prox_solve_shifted(a->B0, a->ainv_pool, a->W0, a->b0, G_prev, a->dual, c2, n, has_b, rho, a->eta,
+                                      plan.rho[1], shift_terms(rho, a->eta, plan.rho[1]), a->wstar, bstar, a->prox_ws,
+                                      a->prox_ws_bytes, s_main));
+    else
+      ADMM_RC(effq_prox_solve(a->B0, Ainv, a->W0, a->b0, G_prev, a->dual, c2, n, has_b, rho, a->eta, a->wstar, bstar,
+                              a->prox_ws, a->prox_ws_bytes, s_main));
+    if (bucket)
+      ADMM_RC(effq_fixed_point_bucket(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
+                                      a->fp_ws, a->fp_ws_bytes, s_main));
+    else
+      ADMM_RC(effq_fixed_point_coop(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
+                                    a->red_ws, s_main));
+    ADMM_RC(effq_project_dual_checked(a->v, a->wstar, st, a->w_levels, G, a->dual, dual_div, Gq, nw, a->err_flag,
+                                      s_main));
+    // ---- the loss of this iterate (loss stream) ----
+    if (fork_loss) {
+      hipEvent_t e = ev_main[i % EV_POOL];
+      ADMM_HIP(hipEventRecord(e, s_main));
+      ADMM_HIP(hipStreamWaitEvent(s_loss, e, 0));
+    }
+    double* sq = a->hist + 2 * (size_t)i;
+    if (a->loss_kind == 1)
+      ADMM_RC(conv3d_calib_step_i8(a->xidx, Gq, bstar, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, st,
+                                   a->w_levels, sq, a->conv_ws, a->conv_ws_bytes, s_loss));
+    else if (a->loss_kind == 2)
+      ADMM_RC(conv3d_calib_step_i8s(a->xidx, Gq, bstar, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, st,
+                                    a->w_levels, i == 0 ? 1 : 0, sq, a->conv_ws, a->conv_ws_bytes, s_loss));
+    else
+      ADMM_RC(conv3d_quant_calib_step(a->xq, G, bstar, a->y_fp, nullptr, &a->geom, nullptr, 0, sq, nullptr, a->conv_ws,
+                                      a->conv_ws_bytes, s_loss));   // unweighted MSE (quirk Q5)
+    if (i % a->rho_period == 0) rho = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
+  }
+  // join: everything the caller reads next (hist, rings) is ordered on the main stream
+  if (fork_loss) {
+    ADMM_HIP(new_event(&ev_join_loss));
+    ADMM_HIP(hipEventRecord(ev_join_loss, s_loss));
+    ADMM_HIP(hipStreamWaitEvent(s_main, ev_join_loss, 0));
+  }
+  if (fork_side && n_inv > 1) {
+    ADMM_HIP(new_event(&ev_join_side));
+    ADMM_HIP(hipEventRecord(ev_join_side, s_side));
+    ADMM_HIP(hipStreamWaitEvent(s_main, ev_join_side, 0));
+  }
+  destroy_events();
+#undef ADMM_HIP
+#undef ADMM_RC
+  return EFFQ_OK;
+}
+
+int effq_admm_select_best(const double* hist, int iters, const float* G_ring, const float* b_ring, size_t nw, size_t nb,
+                          float* best_G, float* best_b, double* best_out, void* stream) {
+  EFFQ_CHECK_ARG(hist && G_ring && best_G && best_out && iters > 0 && nw > 0);
+  EFFQ_CHECK_ARG((b_ring == nullptr) == (best_b == nullptr));
+  size_t blocks = (nw + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_select_best, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), hist, iters, G_ring, b_ring,
+                     nw, nb, best_G, best_b, best_out);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+}  // extern "C"

@@ -17,6 +17,7 @@ from ._lib import Geom, check
 ADMM_TOL = 1e-5   # layer_helper.py:55
 import os as _os
 COOP_FIXED_POINT = _os.environ.get("EFFQ_COOP_FP", "1") != "0"
+BUCKET_FIXED_POINT = _os.environ.get("EFFQ_BUCKET_FP", "1") != "0"
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -245,6 +246,15 @@ class HipOps:
         _, it, _ = self.fit_scale(v, levels, -1.0, 1.0, guess_iters=guess, state=state)
         return it
 
+    def fixed_point_bucket(self, a, b, v, levels: int, state, lo: float = -1.0, hi: float = 1.0):
+        """project_by_iter of v = a + b (b may be None) on the bucketed copy: one workgroup, one launch
+        (effq_fixed_point_bucket)."""
+        n = a.numel()
+        ws = self._workspace("fp_bucket", self.lib.effq_fp_bucket_ws_bytes(n))
+        check(self.lib.effq_fixed_point_bucket(_ptr(a), _ptr(b), _ptr(v), n, levels, lo, hi, ADMM_TOL, 100 * levels,
+                                               _ptr(state), _ptr(ws), ws.numel(), self.stream),
+              "effq_fixed_point_bucket")
+
     def fp_check(self, state, err_flag):
         check(self.lib.effq_fp_check(_ptr(state), _ptr(err_flag), self.stream), "effq_fp_check")
 
@@ -421,6 +431,104 @@ class HipOps:
         a.G, a.Gq, a.state = G.data_ptr(), (Gq.data_ptr() if Gq is not None else None), state.data_ptr()
         a.rho, a.rho_inv, a.shift_terms, a.dual_div = float(rho), float(rho_inv), int(shift_terms), float(dual_div)
         check(self.lib.effq_admm_chain_step(C.byref(a), self.stream), "effq_admm_chain_step")
+
+    # -- the whole ADMM loop of a layer in one binding call ---------------------------------------------
+    def admm_run(self, A0, B0, W0, b0, geom: Geom, y_ndhwc, *, xq=None, xidx=None, act_alpha=None, act_levels: int = 0,
+                 loss_kind: int = 0, rho: float, rho_max: float, eta: float, iters: int, period: int, levels: int,
+                 overlap: bool = True):
+        """effq_admm_run: enqueue `iters` ADMM iterations (chain on the current stream, per-iteration loss on the
+        loss stream, later inverses on the side stream).  Returns a handle with the rings and `hist` (iters x 2
+        device doubles, sums of squared errors); no host synchronisation."""
+        from types import SimpleNamespace
+        c2, n = (int(i) for i in B0.shape)
+        has_b = b0 is not None
+        W0 = self._f32(W0)
+        nw = W0.numel()
+        y = self._f32(y_ndhwc)
+        _check_shapes(geom, xq if loss_kind == 0 else xidx, W0, b0, y)
+        if tuple(A0.shape) != (n, n) or nw != c2 * (n - int(has_b)):
+            raise _lib.EffqError("admm_run: A0/B0/W0 shapes do not match")
+        n_inv = self.lib.effq_admm_num_inverses(float(rho), float(rho_max), int(iters), int(period))
+        if n_inv < 1:
+            raise _lib.EffqError("admm_run: bad rho schedule")
+        dev, f32 = self.device, torch.float32
+        ld = self.lib.effq_ainv_ld(n)
+        r = SimpleNamespace(iters=int(iters), nw=nw, c2=c2, has_b=has_b)
+        r.ainv = torch.empty(n_inv, n, ld, dtype=f32, device=dev)
+        r.dual = torch.empty(nw, dtype=f32, device=dev)
+        r.wstar = torch.empty(nw, dtype=f32, device=dev)
+        r.v = torch.empty(nw, dtype=f32, device=dev)
+        r.G_ring = torch.empty(iters, nw, dtype=f32, device=dev)
+        r.Gq_ring = torch.empty(iters, nw, dtype=torch.int8, device=dev) if loss_kind != 0 else None
+        r.b_ring = torch.empty(iters, c2, dtype=f32, device=dev) if has_b else None
+        r.state_ring = torch.zeros(iters, 5, dtype=torch.float64, device=dev)
+        r.hist = torch.zeros(iters, 2, dtype=torch.float64, device=dev)
+        r.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        main = torch.cuda.current_stream(dev)
+        loss_s = self.loss_stream() if overlap else None
+        side_s = self.side_stream()
+        # workspaces are (zero-)filled on the current stream, ahead of the events the library orders the other
+        # streams by
+        prox = self._workspace("prox", self.lib.effq_prox_ws_bytes(c2, n))
+        inv = self._workspace("inv", self.lib.effq_spd_inverse_ws_bytes(n))
+        inv_side = self._workspace("inv_side", self.lib.effq_spd_inverse_ws_bytes(n)) if n_inv > 1 else None
+        fpw = (self._workspace("fp_bucket", self.lib.effq_fp_bucket_ws_bytes(nw))
+               if nw <= self.lib.effq_fp_bucket_max() and BUCKET_FIXED_POINT else None)
+        if loss_kind == 1:
+            cws = self._workspace("conv_i8", self.lib.effq_conv_i8_ws_bytes(C.byref(geom)))
+        elif loss_kind == 2:
+            cws = self._workspace("conv_i8s", self.lib.effq_conv_i8s_ws_bytes(C.byref(geom), int(act_levels),
+                                                                             int(levels)))
+        else:
+            cws = self._workspace("conv", self.lib.effq_conv_ws_bytes(C.byref(geom)))
+        al = self._f32(act_alpha.reshape(1)) if (act_alpha is not None and loss_kind != 0) else None
+        a = _lib.AdmmRunArgs()
+        p = lambda t: None if t is None else t.data_ptr()
+        a.A0, a.B0, a.W0, a.b0 = p(self._f32(A0)), p(self._f32(B0)), p(W0), p(b0)
+        a.c2, a.n, a.has_bias, a.w_levels = c2, n, int(has_b), int(levels)
+        a.iters, a.rho_period = int(iters), int(period)
+        a.rho, a.rho_max, a.eta, a.tol = float(rho), float(rho_max), float(eta), ADMM_TOL
+        a.geom = geom
+        a.loss_kind, a.act_levels = int(loss_kind), int(act_levels)
+        a.xq = p(self._f32(xq)) if loss_kind == 0 else None
+        a.xidx = p(xidx) if loss_kind != 0 else None
+        a.y_fp, a.act_alpha_dev = p(y), p(al)
+        a.dual, a.wstar, a.v = p(r.dual), p(r.wstar), p(r.v)
+        a.G_ring, a.Gq_ring, a.b_ring = p(r.G_ring), p(r.Gq_ring), p(r.b_ring)
+        a.state_ring, a.hist, a.err_flag = p(r.state_ring), p(r.hist), p(r.err)
+        a.ainv_pool, a.n_ainv = p(r.ainv), n_inv
+        a.prox_ws, a.prox_ws_bytes = p(prox), prox.numel()
+        a.red_ws = p(self._red_ws)
+        a.fp_ws, a.fp_ws_bytes = p(fpw), (fpw.numel() if fpw is not None else 0)
+        a.inv_ws, a.inv_ws_bytes = p(inv), inv.numel()
+        a.inv_ws_side, a.inv_ws_side_bytes = p(inv_side), (inv_side.numel() if inv_side is not None else 0)
+        a.conv_ws, a.conv_ws_bytes = p(cws), cws.numel()
+        a.stream_main = main.cuda_stream
+        a.stream_loss = loss_s.cuda_stream if loss_s is not None else None
+        a.stream_side = side_s.cuda_stream if inv_side is not None else None
+        r.keep = (A0, B0, W0, b0, y, xq, xidx, al)       # the call only enqueues: keep every operand alive
+        check(self.lib.effq_admm_run(C.byref(a)), "effq_admm_run")
+        return r
+
+    def admm_select_best(self, run):
+        """Earliest iterate with the smallest (already all-reduced) loss: (best_G, best_b, best[loss sum, index])."""
+        best_G = torch.empty(run.nw, dtype=torch.float32, device=self.device)
+        best_b = torch.empty(run.c2, dtype=torch.float32, device=self.device) if run.has_b else None
+        best = torch.empty(2, dtype=torch.float64, device=self.device)
+        check(self.lib.effq_admm_select_best(_ptr(run.hist), run.iters, _ptr(run.G_ring), _ptr(run.b_ring), run.nw,
+                                             run.c2, _ptr(best_G), _ptr(best_b), _ptr(best), self.stream),
+              "effq_admm_select_best")
+        return best_G, best_b, best
+
+    @staticmethod
+    def admm_read(run, best):
+        """ONE device->host copy per layer: loss history, best, the last scale, fixed-point iteration counts, error."""
+        pack = torch.cat([run.hist[:, 0], best, run.state_ring[-1, :1], run.state_ring[:, 4],
+                          run.err.to(torch.float64)]).cpu()
+        it = run.iters
+        w_iters = pack[it + 3: 2 * it + 3].contiguous().view(torch.int32)[0::2].tolist()
+        return dict(hist=pack[:it].tolist(), best=pack[it:it + 2].tolist(), alpha_w=float(pack[it + 2]),
+                    w_iters=w_iters, err=int(pack[-1]))
 
     def shift_terms(self, rho: float, eta: float, rho_inv: float) -> int:
         d = rho_inv - rho

@@ -286,149 +286,31 @@ class EfficientQConvHIP(PTQConv):
         red(A0)
         red(B0)
 
-        f32 = dict(dtype=torch.float32, device=dev)
-        # The loss of iteration i (conv + MSE + keep-best) only feeds the best-iterate selection; the chain
-        # prox -> scale fixed point -> projection/dual of iteration i+1 does not wait for it.  Everything the
-        # loss reads is kept per iteration parity (G, its int8 numerators, the bias, the scale state), so the
-        # loss stream evaluates iteration i while the calibration stream computes i+1.
-        Gb = [torch.empty_like(W0), W0.clone()]              # G(i) lives in Gb[i & 1]; G(-1) = W0
-        dual = torch.zeros_like(W0)
-        wstar = torch.empty_like(W0)
-        v = torch.empty_like(W0)
-        bsb = [torch.empty(c2, **f32), torch.empty(c2, **f32)] if has_b else [None, None]
-        best_G = torch.empty_like(W0)
-        best_b = torch.empty(c2, **f32) if has_b else None
-        sqerr = torch.zeros(2, dtype=torch.float64, device=dev)
-        best = torch.zeros(4, dtype=torch.float64, device=dev)
-        stb = [ops.new_fp_state(), ops.new_fp_state()]
-        Gqb = [torch.empty(W0.shape, dtype=torch.int8, device=dev) for _ in range(2)] if int_conv else [None, None]
-        fp_err = torch.zeros(1, dtype=torch.int32, device=dev)
-        loss_s = getattr(ops, "loss_stream", lambda: None)() if self.lwq_overlap_loss else None
-        main_s = torch.cuda.current_stream(dev) if loss_s is not None else None
-        ev_loss = [None, None]
-        # events are reused per iteration parity (a wait captures the record that precedes it), and the library ops
-        # are pinned to their stream instead of looking torch's current stream up on every call
-        ev_main = [torch.cuda.Event(), torch.cuda.Event()] if loss_s is not None else None
-        ev_done = [torch.cuda.Event(), torch.cuda.Event()] if loss_s is not None else None
-        pin = getattr(ops, "on_stream", None)
-        if pin is not None:
-            ops.restore_stream(None)     # (a pin left behind by an earlier exception)
-        # torch-side work inside the loss step follows torch's CURRENT stream: the collectives of the data-parallel
-        # reducer and the .item() of the trace need the stream context, the plain library ops only the pin
-        needs_ctx = bool(red) or bool(self.lwq_trace)
-        # A = A0 + rho*I' + eta*I changes only with rho, and the rho schedule is known up front (5 values per
-        # layer): the first inverse is formed on the calibration stream, the later ones on a side stream under
-        # the ADMM iterations that precede their first use (EfficientQConv.py:129-137 fixes when that is).
-        rhos, r_ = [], rho
-        for i in range(self.lwq_iter):
-            if not rhos or rhos[-1] != r_:
-                rhos.append(r_)
-            if i % RHO_PERIOD == 0:
-                r_ = r_ * 2 if r_ * 2 <= rho_m else rho_m
-        # rhos[0] serves iteration 0 only (the schedule doubles right after it): no inverse is formed for it,
-        # its solve runs as fixed-point sweeps through the inverse of A(rhos[1]) (effq_prox_solve_shifted)
-        shifted_first = len(rhos) > 1 and rhos[1] > rhos[0] and hasattr(ops, "prox_solve_shifted")
-        first = 1 if shifted_first else 0
-        inv_of = {rhos[first]: (ops.spd_inverse(A0, has_b, rhos[first], eta), None)}
-        side = getattr(ops, "side_stream", lambda: None)()
-        if side is not None and len(rhos) > first + 1:
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for r_ in rhos[first + 1:]:
-                    buf = ops.spd_inverse(A0, has_b, r_, eta, ws_key="inv_side")
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    inv_of[r_] = (buf, ev)
-        main_pin = pin(main_s) if (pin is not None and main_s is not None) else None
-        chain = None
-        if hasattr(ops, "new_chain") and ops.chain_supported(W0.numel()):
-            chain = ops.new_chain(B0, W0, b0, dual, wstar, v, fp_err, self.qlvl_w, eta)
-        Ainv, rho_of_inv = None, None
+        # The 200 iterations (:99-144) are enqueued by ONE library call (effq_admm_run): the serial chain prox ->
+        # scale fixed point -> projection/dual on this stream, the loss of iteration i (conv + MSE, used only to pick
+        # the best iterate) on a second stream while the chain computes i+1, the inverses of A(rho) for the later rho
+        # values (A changes only with rho: 4 inverses per layer, not 200 LU solves) on a third.  Per-iteration results
+        # stay in rings, the squared errors in `hist`; the best iterate is selected afterwards - so the data-parallel
+        # reduction of the 200 losses is ONE collective per layer.
         import time as _time
         t_loop0 = _time.perf_counter()
-        guess = 16
-        a_w = 1.0
-        w_iters, hist = [], []
-        for i in range(self.lwq_iter):                                     # (:99-144)
-            use_shift = shifted_first and i == 0
-            if rho_of_inv != rho and not use_shift:   # A changes only with rho: 4 inverses per layer, not 200 LU solves
-                if rho not in inv_of:
-                    inv_of[rho] = (ops.spd_inverse(A0, has_b, rho, eta), None)
-                Ainv, ev = inv_of[rho]
-                if ev is not None:
-                    torch.cuda.current_stream(dev).wait_event(ev)
-                rho_of_inv = rho
-            p_ = i & 1
-            if ev_loss[p_] is not None:             # the loss of iteration i-2 is done with this parity's buffers
-                main_s.wait_event(ev_loss[p_])
-            G, Gq, bstar, st_w = Gb[p_], Gqb[p_], bsb[p_], stb[p_]
-            dual_div = 1.0
-            if i % RHO_PERIOD == 0:                                        # (:129-137)
-                dual_div = 2.0 if rho * 2 <= rho_m else rho_m / rho
-            if chain is not None:      # prox -> fixed point -> check -> projection in ONE binding call
-                if use_shift:
-                    ops.chain_step(chain, inv_of[rhos[1]][0], Gb[p_ ^ 1], bstar, G, Gq, st_w, rho, dual_div,
-                                   rhos[1], ops.shift_terms(rho, eta, rhos[1]))
-                else:
-                    ops.chain_step(chain, Ainv, Gb[p_ ^ 1], bstar, G, Gq, st_w, rho, dual_div)
-            else:
-                if use_shift:
-                    ops.prox_solve_shifted(B0, inv_of[rhos[1]][0], W0, b0, Gb[p_ ^ 1], dual, rho, eta, rhos[1], wstar,
-                                           bstar)
-                else:
-                    ops.prox_solve(B0, Ainv, W0, b0, Gb[p_ ^ 1], dual, rho, eta, wstar, bstar)
-                it_w = ops.weight_fixed_point(wstar, dual, v, self.qlvl_w, st_w, guess)   # (:108) no host sync
-                ops.fp_check(st_w, fp_err)                                                # when the tensor is small
-                if it_w is not None:
-                    guess = it_w + 2
-                    w_iters.append(it_w)
-                ops.admm_project_dual(v, wstar, st_w, self.qlvl_w, G, dual, dual_div, Gq if int_conv else None)
-
-            def loss_step(i=i, G=G, Gq=Gq, bstar=bstar, st_w=st_w):
-                if use_i8:
-                    ops.conv_step_i8(xidx, Gq, bstar, geom, yn, self.alpha_act.data, self.qlvl_act, st_w,
-                                     self.qlvl_w, sqerr)
-                elif use_i8s:
-                    ops.conv_step_i8s(xidx, Gq, bstar, geom, yn, self.alpha_act.data, self.qlvl_act, st_w,
-                                      self.qlvl_w, sqerr, i == 0)
-                else:
-                    ops.conv_step(xq, G, bstar, geom, yn, None, sqerr=sqerr)   # unweighted MSE (quirk Q5)
-                red(sqerr)
-                if self.lwq_trace:
-                    hist.append(sqerr[0].item())
-                ops.admm_keep_best(sqerr, best, i, G, bstar, best_G, best_b)
-
-            if loss_s is None:
-                loss_step()
-            else:
-                ev_main[p_].record(main_s)
-                loss_s.wait_event(ev_main[p_])
-                prev_pin = pin(loss_s) if pin is not None else None
-                if needs_ctx or pin is None:
-                    with torch.cuda.stream(loss_s):
-                        loss_step()
-                else:
-                    loss_step()
-                if pin is not None:
-                    ops.restore_stream(prev_pin)
-                ev_done[p_].record(loss_s)
-                ev_loss[p_] = ev_done[p_]
-            if i % RHO_PERIOD == 0:
-                rho = rho * 2 if rho * 2 <= rho_m else rho_m
-
-        if pin is not None and main_s is not None:
-            ops.restore_stream(main_pin)
+        loss_kind = 1 if use_i8 else (2 if use_i8s else 0)
+        run = ops.admm_run(A0, B0, W0, b0, geom, yn, xq=xq, xidx=xidx, act_alpha=self.alpha_act.data,
+                           act_levels=self.qlvl_act, loss_kind=loss_kind, rho=rho, rho_max=rho_m, eta=eta,
+                           iters=self.lwq_iter, period=RHO_PERIOD, levels=self.qlvl_w,
+                           overlap=self.lwq_overlap_loss)
         t_enq = _time.perf_counter() - t_loop0     # host time to enqueue the 200 iterations (diagnostic)
-        if side is not None:
-            torch.cuda.current_stream(dev).wait_stream(side)
-        if loss_s is not None:
-            torch.cuda.current_stream(dev).wait_stream(loss_s)
-        a_w, _, _ = ops.read_fp_state(stb[(self.lwq_iter - 1) & 1])        # one sync per layer
+        red(run.hist)
+        best_G, best_b, best = ops.admm_select_best(run)
+        info = ops.admm_read(run, best)                                    # one host sync per layer
+        t_loop = _time.perf_counter() - t_loop0
+        a_w, w_iters, hist, best_h = info["alpha_w"], info["w_iters"], info["hist"], info["best"]
+        if info["err"] != 0:                                               # layer_helper.py:62-64
+            if info["err"] == 2:
+                raise RuntimeWarning(f'Exceed maximum iteration ({100 * self.qlvl_w}) for alpha optimization')
+            raise RuntimeError(f'weight-scale fixed point did not finish (device state {info["err"]})')
         if hasattr(ops, "release_retired"):
             ops.release_retired()        # every stream was joined and the host has synchronised
-        t_loop = _time.perf_counter() - t_loop0
-        if fp_err.item() != 0:                                             # layer_helper.py:62-64
-            raise RuntimeWarning(f'Exceed maximum iteration ({100 * self.qlvl_w}) for alpha optimization')
         self.weight.data = best_G.reshape(self.weight.shape)               # (:147-158)
         if has_b:
             self.bias.data = best_b
@@ -436,7 +318,7 @@ class EfficientQConvHIP(PTQConv):
 
         _, fin = ops.conv_step(xq, best_G, best_b, geom, yn, att)          # (:161-166)
         red(fin)
-        fin_h, best_h = fin.tolist(), best.tolist()
+        fin_h = fin.tolist()
         numel = y_dim * 1.0
         lossf = (fin_h[1] if att is not None else fin_h[0]) / numel
         if self.layer_loss is not None:

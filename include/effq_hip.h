@@ -116,6 +116,17 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
 size_t effq_fp_coop_max(void);
 int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                           double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream);
+/* Same contract again (n <= effq_fp_bucket_max(), levels <= 256), ONE workgroup and no per-iteration pass over the
+ * tensor: the values are counted into equal-width buckets (exact integer sum per bucket) and regrouped by bucket once;
+ * each iteration then reads prefix tables and classifies only the values of the bucket a level boundary falls into,
+ * with the reference's arithmetic.  Level counts are exactly the reference's, alpha agrees to ~1e-14 relative (fp64
+ * sums in another order), same iteration count; deterministic.  ws: effq_fp_bucket_ws_bytes(n), no initialisation
+ * needed (the regrouped copy of v). */
+size_t effq_fp_bucket_max(void);
+size_t effq_fp_bucket_ws_bytes(size_t n);
+int effq_fixed_point_bucket(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                            double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
+                            void* stream);
 /* Sticky device-side check used by stream-resident loops: *err_flag_dev = 2 (cap hit; the reference
  * raises, layer_helper.py:62-64) or 3 (not finished) unless state.done == 1. */
 int effq_fp_check(const effq_fp_state* state_dev, int32_t* err_flag_dev, void* stream);
@@ -250,6 +261,53 @@ typedef struct effq_chain_args {
   float dual_div;
 } effq_chain_args;
 int effq_admm_chain_step(const effq_chain_args* a, void* stream);
+
+/* ---- the whole ADMM loop of a layer in ONE call (EfficientQConv.py:99-144) -----------------------------------
+ * Enqueues `iters` iterations of { prox solve, weight-scale fixed point, projection + dual update } on stream_main,
+ * the loss of each iterate (conv + squared error against y_fp, the reference's per-iteration F.conv3d + F.mse_loss)
+ * on stream_loss one iteration behind, and the inverses of A(rho) for the later rho values on stream_side.  stream_loss
+ * / stream_side may be NULL (that work then runs on stream_main).  No host synchronisation; on return stream_main is
+ * ordered after everything the call enqueued on the other two.
+ * Results are kept PER ITERATION (slot i of each ring is written once and never reused, so the three streams need no
+ * back-pressure): G_ring [iters][nw] projected weights, Gq_ring [iters][nw] their int8 operands (required for
+ * loss_kind 1/2, else may be NULL), b_ring [iters][c2] (NULL without bias), state_ring [iters] scale states
+ * (state_ring[iters-1].alpha is the reference's final alpha_w, quirk Q6), hist [iters][2] = {sum (out-y)^2, same}.
+ * The best iterate is chosen afterwards by effq_admm_select_best(); a data-parallel caller all-reduces hist first
+ * (ONE collective per layer for the 200 per-iteration losses).
+ * rho schedule: after iteration i with i % rho_period == 0, rho doubles while 2*rho <= rho_max (else rho = rho_max)
+ * and dual is divided by the same factor (EfficientQConv.py:129-137).  One inverse per distinct rho that serves more
+ * than one iteration: ainv_pool holds n_ainv >= effq_admm_num_inverses(...) matrices of n*effq_ainv_ld(n) floats.
+ * loss_kind: 0 = conv3d_quant_calib_step on xq (fp32), 1 = conv3d_calib_step_i8, 2 = conv3d_calib_step_i8s (both on
+ * xidx, act_alpha_dev, act_levels).  Workspaces as the respective entry points document them (conv_ws zero-filled
+ * once; red_ws = the reduction workspace; fp_ws = effq_fp_bucket_ws_bytes(nw), may be NULL -> cooperative fixed point;
+ * inv_ws / inv_ws_side = effq_spd_inverse_ws_bytes(n) each, the second only with stream_side).
+ * *err_flag (device int32, zeroed by the caller) is set when a weight fixed point hits its cap (layer_helper.py:62-64). */
+typedef struct effq_admm_run_args {
+  const float* A0; const float* B0; const float* W0; const float* b0;
+  int32_t c2, n, has_bias, w_levels;
+  int32_t iters, rho_period;
+  double rho, rho_max, eta, tol;
+  effq_geom geom;
+  int32_t loss_kind, act_levels;
+  const float* xq; const uint8_t* xidx; const float* y_fp; const float* act_alpha_dev;
+  float* dual; float* wstar; float* v;
+  float* G_ring; int8_t* Gq_ring; float* b_ring; effq_fp_state* state_ring; double* hist;
+  int32_t* err_flag;
+  float* ainv_pool; int32_t n_ainv;
+  void* prox_ws; size_t prox_ws_bytes;
+  void* red_ws;
+  void* fp_ws; size_t fp_ws_bytes;
+  void* inv_ws; size_t inv_ws_bytes;
+  void* inv_ws_side; size_t inv_ws_side_bytes;
+  void* conv_ws; size_t conv_ws_bytes;
+  void* stream_main; void* stream_loss; void* stream_side;
+} effq_admm_run_args;
+int effq_admm_num_inverses(double rho, double rho_max, int iters, int rho_period);
+int effq_admm_run(const effq_admm_run_args* a);
+/* best = the EARLIEST iterate with the smallest hist[i][0] ("if i == 0 or lossf < best", EfficientQConv.py:139-142):
+ * copies its G / b* out of the rings; best_out[0] = its loss sum, best_out[1] = its index (as a double). */
+int effq_admm_select_best(const double* hist, int iters, const float* G_ring, const float* b_ring, size_t nw, size_t nb,
+                          float* best_G, float* best_b, double* best_out, void* stream);
 
 /* ---- f2: bit-packed storage of level ids ---------------------------------------------------
  * The reference stores one uint8 per weight (store_int_weight, PTQConv.py:125-152); these pack the level ids

@@ -129,6 +129,52 @@ class OracleOps:
         G.copy_(g)
         dual.copy_(d)
 
+    # the whole loop (the product issues it through effq_admm_run; same order of operations, EfficientQConv.py:99-144)
+    def admm_run(self, A0, B0, W0, b0, geom, y_ndhwc, *, xq=None, xidx=None, act_alpha=None, act_levels=0,
+                 loss_kind=0, rho, rho_max, eta, iters, period, levels, overlap=True):
+        from types import SimpleNamespace
+        has_b = b0 is not None
+        c2 = B0.shape[0]
+        G = W0.clone()
+        dual = torch.zeros_like(W0)
+        wstar, v = torch.empty_like(W0), torch.empty_like(W0)
+        r = SimpleNamespace(iters=iters, nw=W0.numel(), c2=c2, has_b=has_b, G_ring=[], b_ring=[] if has_b else None,
+                            hist=torch.zeros(iters, 2, dtype=torch.float64), w_iters=[], alpha_w=None)
+        st = self.new_fp_state()
+        for i in range(iters):
+            A = self.spd_inverse(A0, has_b, rho, eta)
+            bstar = torch.empty(c2) if has_b else None
+            self.prox_solve(B0, A, W0, b0, G, dual, rho, eta, wstar, bstar)
+            r.w_iters.append(self.weight_fixed_point(wstar, dual, v, levels, st))
+            dual_div = 1.0
+            if i % period == 0:
+                dual_div = 2.0 if rho * 2 <= rho_max else rho_max / rho
+            Gn = torch.empty_like(W0)
+            self.admm_project_dual(v, wstar, st, levels, Gn, dual, dual_div)
+            _, sq = self.conv_step(xq, Gn, bstar, geom, y_ndhwc)
+            r.hist[i] = sq
+            r.G_ring.append(Gn)
+            if has_b:
+                r.b_ring.append(bstar)
+            G = Gn
+            if i % period == 0:
+                rho = rho * 2 if rho * 2 <= rho_max else rho_max
+        r.alpha_w = st[0].item()
+        return r
+
+    def admm_select_best(self, run):
+        h = run.hist[:, 0].tolist()
+        bi = 0
+        for i in range(1, run.iters):
+            if h[i] < h[bi]:
+                bi = i
+        best = torch.tensor([h[bi], float(bi)], dtype=torch.float64)
+        return run.G_ring[bi].clone(), (run.b_ring[bi].clone() if run.has_b else None), best
+
+    @staticmethod
+    def admm_read(run, best):
+        return dict(hist=run.hist[:, 0].tolist(), best=best.tolist(), alpha_w=run.alpha_w, w_iters=run.w_iters, err=0)
+
     def admm_keep_best(self, sqerr, best, it, G, b, best_G, best_b):
         if it == 0 or sqerr[0].item() < best[0].item():
             best_G.copy_(G)

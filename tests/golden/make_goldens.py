@@ -246,9 +246,11 @@ def g5b():
     for tag, kw in {
         "c32": dict(c1=32, c2=32, k=3, stride=1, pad=1, N=2, S=12, L_w=4, L_a=4, q_act=True, seed=2024,
                     with_mask=True),
-        "c64": dict(c1=64, c2=64, k=3, stride=1, pad=1, N=2, S=8, L_w=4, L_a=4, q_act=True, seed=2025,
+        # (V = 2 * 12^3 = 3456 output voxels for n = 1729 unknowns: an over-determined system like the real layers)
+        "c64": dict(c1=64, c2=64, k=3, stride=1, pad=1, N=2, S=12, L_w=4, L_a=4, q_act=True, seed=2025,
                     with_mask=True),
     }.items():
+        sub = 2 if tag == "c64" else 1          # fwd_q is kept on every sub-th voxel per axis (fixture size)
         recs = {}
         for nt in (1, 8):
             torch.set_num_threads(nt)
@@ -260,9 +262,11 @@ def g5b():
         out[f"{tag}_mask_full"] = base["mask_full"].to(torch.uint8)
         for nt, rec in recs.items():
             assert torch.equal(rec["x"], base["x"]) and torch.equal(rec["y"], base["y"])
+            rec["fwd_q"] = rec["fwd_q"][:, :, ::sub, ::sub, ::sub].contiguous()
             for k in ("loss_hist", "final_mse", "aw_hist", "weight", "bias", "alpha_w", "alpha_act", "layer_loss",
                       "fwd_q"):
                 out[f"{tag}_t{nt}_{k}"] = rec[k]
+        out[f"{tag}_fwd_sub"] = np.int64(sub)
         a, b = recs[1], recs[8]
         L = kw["L_w"]
         lv = lambda t: torch.round((t / t.abs().max() + 1) * (L - 1) / 2)

@@ -508,6 +508,90 @@ def test_cooperative_weight_fixed_point_matches_oracle(ops, n, L):
     assert ops.read_fp_state(st2) == (alpha, iters, done)
 
 
+# ------------------------------------------------------------------ a2: bucketed single-workgroup fixed point
+def _run_bucket(ops, a, b, L, lo=-1.0, hi=1.0):
+    v = torch.empty(a.numel(), device="cuda:0") if b is not None else None
+    st = ops.new_fp_state()
+    ops.fixed_point_bucket(dev(a), None if b is None else dev(b), v, L, st, lo, hi)
+    return ops.read_fp_state(st), v
+
+
+@pytest.mark.parametrize("L", [4, 16, 256])
+def test_bucketed_fixed_point_matches_reference_goldens(ops, gold, L):
+    """effq_fixed_point_bucket against G2 (the reference's project_by_iter on weights AND on ReLU activations):
+    alpha <= 1e-11 relative, equal iteration count, and the level ids at that alpha bit-exact."""
+    g = gold("g2_project.npz")
+    for key, lo in (("wgt", -1.0), ("act", 0.0)):
+        x = T(g[key]).reshape(-1).contiguous()
+        (alpha, iters, done), _ = _run_bucket(ops, x, None, L, lo, 1.0)
+        want_a, want_it = float(g[f"{key}_L{L}_alpha"]), int(g[f"{key}_L{L}_iters"])
+        assert done == 1 and iters == want_it, (key, L, iters, want_it)
+        assert abs(alpha - want_a) <= 1e-11 * want_a
+        st = ops.new_fp_state()
+        st[0] = alpha
+        _, _, idx = ops.quant_dequant_f64path(dev(x), st, L, lo, 1.0, want_idx=True)
+        assert torch.equal(idx.cpu().reshape(-1), T(g[f"{key}_L{L}_idx"]).reshape(-1).to(torch.uint8))
+
+
+@pytest.mark.parametrize("n,L", [(96, 256), (3456, 256), (2048, 4), (27648, 4), (27648, 16), (32768, 8), (110592, 4),
+                                 (110592, 16), (442368, 4), (300001, 256), (524288, 2), (5, 4), (1, 4)])
+def test_bucketed_fixed_point_matches_oracle(ops, n, L):
+    gen = torch.Generator().manual_seed(7 * n + L)
+    w = torch.randn(n, generator=gen) * 0.05
+    du = torch.randn(n, generator=gen) * 0.005
+    (alpha, iters, done), v = _run_bucket(ops, w, du, L)
+    vsum = w + du
+    assert torch.equal(v.cpu(), vsum)
+    fit = O.fit_scale(vsum, L, -1, 1)
+    assert done == 1 and iters == fit.iters, (done, iters, fit.iters)
+    assert abs(alpha - fit.alpha) <= 1e-11 * abs(fit.alpha)
+    (a2, i2, d2), _ = _run_bucket(ops, w, du, L)                     # deterministic: bit-identical on repetition
+    assert (a2, i2, d2) == (alpha, iters, done)
+    if n <= ops.lib.effq_fp_small_max():                              # and the all-values kernel agrees
+        st = ops.new_fp_state()
+        vv = torch.empty(n, device="cuda:0")
+        ops.weight_fixed_point(dev(w), dev(du), vv, L, st)
+        a3, i3, d3 = ops.read_fp_state(st)
+        assert i3 == iters and abs(a3 - alpha) <= 1e-12 * abs(alpha)
+
+
+@pytest.mark.parametrize("L", [2, 3, 4, 5, 16, 256])
+def test_bucketed_fixed_point_on_adversarial_values(ops, L):
+    """Values sitting ON level boundaries of intermediate scales, exact zeros, tiny negatives (where 1 - |v/a| rounds
+    to 1), duplicates, a heavy outlier (almost everything in one bucket), all-equal tensors."""
+    gen = torch.Generator().manual_seed(1234 + L)
+    base = torch.randn(20000, generator=gen) * 0.1
+    fit0 = O.fit_scale(base, L, -1, 1)
+    d = 2.0 / (L - 1)
+    cases = {}
+    # boundaries (k - 0.5) * d - 1 at the converged scale and at the start scale, hit exactly and one ulp either side
+    bnd = torch.tensor([(k - 0.5) * d - 1.0 for k in range(1, L)], dtype=torch.float64)
+    pts = []
+    for a in (fit0.alpha, base.abs().double().mean().item()):
+        p = (bnd * a).float()
+        pts += [p, torch.nextafter(p, torch.tensor(10.0)), torch.nextafter(p, torch.tensor(-10.0))]
+    cases["on boundaries"] = torch.cat([base] + pts * 7)
+    cases["zeros and tiny"] = torch.cat([base, torch.zeros(500), -torch.zeros(300), torch.full((200,), -1e-30),
+                                         torch.full((200,), 1e-30), torch.full((100,), -1e-42)])
+    cases["duplicates"] = torch.round(base * 50) / 50
+    out = base.clone()
+    out[0] = 500.0
+    cases["outlier"] = out
+    cases["all equal"] = torch.full((5000,), 0.37)
+    cases["two values"] = torch.cat([torch.full((3000,), -0.2), torch.full((2000,), 0.9)])
+    for name, x in cases.items():
+        try:
+            fit = O.fit_scale(x, L, -1, 1)
+        except RuntimeWarning:
+            fit = None
+        (alpha, iters, done), _ = _run_bucket(ops, x.contiguous(), None, L)
+        if fit is None:
+            assert done == 2, name
+            continue
+        assert done == 1 and iters == fit.iters, (name, L, done, iters, fit.iters)
+        assert abs(alpha - fit.alpha) <= 1e-11 * abs(fit.alpha), (name, alpha, fit.alpha)
+
+
 @pytest.mark.parametrize("bits,levels,n", [(2, 4, 27648), (4, 16, 1001), (1, 2, 77), (8, 256, 513), (2, 3, 5), (4, 16, 0)])
 def test_bit_packed_level_storage_round_trip(ops, bits, levels, n):
     """Row f2: level ids packed at 1/2/4/8 bits (the reference keeps one uint8 per weight, PTQConv.py:125-152)."""

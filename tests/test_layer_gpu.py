@@ -83,13 +83,17 @@ def test_wide_layer_calibration_within_reference_self_spread(gold, tag):
         ref_hist = g[f"{tag}_t{nt}_loss_hist"]
         a_ref = float(g[f"{tag}_t{nt}_alpha_act"])
         assert abs(conv.alpha_act.item() - a_ref) <= 1e-6 * a_ref
-        # before the discrete trajectories separate: north_star's bar / 10, or 3x what the reference shows itself
-        bar5 = max(1e-4, 3 * sp["hist_first5"])
-        assert np.all(np.abs(hist[:5] - ref_hist[:5]) <= bar5 * ref_hist[:5]), (hist[:5], ref_hist[:5])
+        # the first iterations, per iteration: north_star's bar / 10, or 3x what the two reference runs show between
+        # themselves at that iteration (at 64 channels the reference's fp32 LU solve at the small first rho already
+        # moves the loss of iteration 0 by 7e-4 between 1 and 8 threads, and its runs separate by iteration 3)
+        self5 = np.abs(g[f"{tag}_t1_loss_hist"][:5] - g[f"{tag}_t8_loss_hist"][:5]) / g[f"{tag}_t8_loss_hist"][:5]
+        bar5 = np.maximum(1e-4, 3 * self5)
+        assert np.all(np.abs(hist[:5] - ref_hist[:5]) <= bar5 * ref_hist[:5]), (hist[:5], ref_hist[:5], bar5)
         d_ll = abs(got_loss - float(g[f"{tag}_t{nt}_layer_loss"])) / float(g[f"{tag}_t{nt}_layer_loss"])
         d_best = abs(hist.min() - ref_hist.min()) / ref_hist.min()
         d_idx = (lv(w) != lv(T(g[f"{tag}_t{nt}_weight"]))).float().mean().item()
-        d_out = _rel_mse(out, T(g[f"{tag}_t{nt}_fwd_q"]))
+        sub = int(g[f"{tag}_fwd_sub"])
+        d_out = _rel_mse(out[:, :, ::sub, ::sub, ::sub], T(g[f"{tag}_t{nt}_fwd_q"]))
         rep[nt] = (d_ll, d_best, d_idx, d_out)
         assert d_ll <= max(1e-3, 3 * sp["layer_loss"]), (d_ll, sp)
         assert d_best <= max(1e-3, 3 * sp["best_mse"]), (d_best, sp)

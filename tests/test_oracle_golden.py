@@ -162,8 +162,8 @@ def test_g5b_wide_layer_bit_exact_per_thread_count(gold, tag, nt):
 
 def test_g5b_reference_self_spread_is_what_the_fixture_says(gold):
     """Recompute the stored spread from the stored runs: reference-vs-reference (1 vs 8 threads) sits at ~3 % output
-    rel-MSE and 5-22 % index mismatch on these layers, i.e. north_star's 1e-3 output bar is not attainable by the
-    reference against itself at >= 32 channels; the first iterations agree to <= 1e-3."""
+    rel-MSE and 5-10 % index mismatch on these layers, i.e. north_star's 1e-3 output bar is not attainable by the
+    reference against itself at >= 32 channels."""
     g = gold("g5b_wide_layers.npz")
     for tag in ("c32", "c64"):
         a, b = T(g[f"{tag}_t1_fwd_q"]), T(g[f"{tag}_t8_fwd_q"])
@@ -171,9 +171,10 @@ def test_g5b_reference_self_spread_is_what_the_fixture_says(gold):
         assert abs(rel - float(g[f"{tag}_spread_out_rel_mse"])) <= 1e-6
         assert rel > 1e-2
         ll = abs(float(g[f"{tag}_t1_layer_loss"]) - float(g[f"{tag}_t8_layer_loss"])) / float(g[f"{tag}_t8_layer_loss"])
-        assert abs(ll - float(g[f"{tag}_spread_layer_loss"])) <= 1e-9 and 1e-4 < ll < 5e-3
-        assert float(g[f"{tag}_spread_hist_first5"]) <= 1e-3
+        assert abs(ll - float(g[f"{tag}_spread_layer_loss"])) <= 1e-9 and 1e-5 < ll < 5e-3
         assert float(g[f"{tag}_spread_idx_mismatch"]) > 0.01
+    # the runs agree at first and separate within a handful of iterations (iteration 5 at 32 channels, 3 at 64)
+    assert float(g["c32_spread_hist_first5"]) <= 1e-5 and float(g["c64_spread_hist_first5"]) >= 1e-3
 
 
 @pytest.mark.parametrize("tag,psz,ov", [("a", 6, 2), ("b", (6, 12, 6), (2, 0, 3)), ("c", 7, 3)])
