@@ -115,7 +115,10 @@ int effq_admm_run(const effq_admm_run_args* a) {
     set_error("admm_run: %zu weights exceed the single-launch fixed points", nw);
     return EFFQ_ERR_ARG;
   }
-  const bool bucket = nw <= effq_fp_bucket_max() && a->fp_ws != nullptr;
+  // weight-scale fixed point, by measured speed on MI355X (scripts/prof_fp.py, microseconds per call at 4 levels:
+  // 2048 values 16 all-values / 22 bucketed; 8192 36 / 28; 27648 84 / 37; 110592 120 / 77; 442368 146 / 107;
+  // 1.77 M 171 / 294 - random-address global atomics; at 256 levels the all-values kernels win at every size)
+  const bool bucket = a->fp_ws != nullptr && a->w_levels <= 16 && nw > 4096 && nw <= ((size_t)1 << 19);
   if (bucket && a->fp_ws_bytes < effq_fp_bucket_ws_bytes(nw)) {
     set_error("admm_run: fixed-point workspace %zu < %zu", a->fp_ws_bytes, effq_fp_bucket_ws_bytes(nw));
     return EFFQ_ERR_WORKSPACE;
@@ -229,6 +232,9 @@ int effq_admm_run(const effq_admm_run_args* a) {
     if (bucket)
       ADMM_RC(effq_fixed_point_bucket(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
                                       a->fp_ws, a->fp_ws_bytes, s_main));
+    else if (nw <= effq_fp_small_max())
+      ADMM_RC(effq_fixed_point_small(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
+                                     s_main));
     else
       ADMM_RC(effq_fixed_point_coop(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
                                     a->red_ws, s_main));

@@ -116,12 +116,15 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
 size_t effq_fp_coop_max(void);
 int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                           double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream);
-/* Same contract again (n <= effq_fp_bucket_max(), levels <= 256), ONE workgroup and no per-iteration pass over the
- * tensor: the values are counted into equal-width buckets (exact integer sum per bucket) and regrouped by bucket once;
- * each iteration then reads prefix tables and classifies only the values of the bucket a level boundary falls into,
- * with the reference's arithmetic.  Level counts are exactly the reference's, alpha agrees to ~1e-14 relative (fp64
- * sums in another order), same iteration count; deterministic.  ws: effq_fp_bucket_ws_bytes(n), no initialisation
- * needed (the regrouped copy of v). */
+/* Same contract again (n <= effq_fp_bucket_max(), levels <= 256) without a per-iteration pass over the tensor: the
+ * values are counted into equal-width buckets (exact integer sum per bucket) and regrouped by bucket once; each
+ * iteration then reads prefix tables and looks only at the values of the bucket a level boundary falls into (those in
+ * a 1e-6 relative guard band around the boundary are classified with the reference's own fp64 arithmetic).  Level
+ * counts are exactly the reference's, alpha agrees to ~1e-14 relative (fp64 sums in another order), same iteration
+ * count; deterministic (integer partial sums).  n <= 32768: one workgroup, everything in LDS, ws unused.  Larger:
+ * four launches (sum|v| and range / count with global atomics / scan / regroup + iterate in the last workgroup to
+ * finish).  ws: effq_fp_bucket_ws_bytes(n) bytes, ZERO-FILLED once by the caller and owned by the library between
+ * calls (its counters are left at zero). */
 size_t effq_fp_bucket_max(void);
 size_t effq_fp_bucket_ws_bytes(size_t n);
 int effq_fixed_point_bucket(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,

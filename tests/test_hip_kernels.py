@@ -533,8 +533,9 @@ def test_bucketed_fixed_point_matches_reference_goldens(ops, gold, L):
         assert torch.equal(idx.cpu().reshape(-1), T(g[f"{key}_L{L}_idx"]).reshape(-1).to(torch.uint8))
 
 
-@pytest.mark.parametrize("n,L", [(96, 256), (3456, 256), (2048, 4), (27648, 4), (27648, 16), (32768, 8), (110592, 4),
-                                 (110592, 16), (442368, 4), (300001, 256), (524288, 2), (5, 4), (1, 4)])
+@pytest.mark.parametrize("n,L", [(96, 256), (3456, 256), (2048, 4), (8191, 4), (16385, 16), (27648, 4), (27648, 16),
+                                 (32768, 8), (32768, 256), (20000, 2), (5, 4), (1, 4), (32769, 4), (110592, 4),
+                                 (110592, 16), (442368, 4), (300001, 256), (1769472, 4), (7077888, 4)])
 def test_bucketed_fixed_point_matches_oracle(ops, n, L):
     gen = torch.Generator().manual_seed(7 * n + L)
     w = torch.randn(n, generator=gen) * 0.05
@@ -553,6 +554,17 @@ def test_bucketed_fixed_point_matches_oracle(ops, n, L):
         ops.weight_fixed_point(dev(w), dev(du), vv, L, st)
         a3, i3, d3 = ops.read_fp_state(st)
         assert i3 == iters and abs(a3 - alpha) <= 1e-12 * abs(alpha)
+
+
+def test_bucketed_fixed_point_across_scales_with_one_workspace(ops):
+    """The multi-workgroup path reuses its workspace: calls on data of very different scale, back to back."""
+    gen = torch.Generator().manual_seed(77)
+    base = torch.randn(150000, generator=gen)
+    for scale in (0.05, 0.5, 0.005, 50.0, 0.05):
+        x = (base * scale).contiguous()
+        fit = O.fit_scale(x, 4, -1, 1)
+        (alpha, iters, done), _ = _run_bucket(ops, x, None, 4)
+        assert done == 1 and iters == fit.iters and abs(alpha - fit.alpha) <= 1e-11 * fit.alpha, (scale, alpha, fit.alpha)
 
 
 @pytest.mark.parametrize("L", [2, 3, 4, 5, 16, 256])
@@ -579,6 +591,10 @@ def test_bucketed_fixed_point_on_adversarial_values(ops, L):
     cases["outlier"] = out
     cases["all equal"] = torch.full((5000,), 0.37)
     cases["two values"] = torch.cat([torch.full((3000,), -0.2), torch.full((2000,), 0.9)])
+    big = {f"{k} (multi-workgroup path)": torch.cat([v, torch.randn(40000, generator=gen) * 0.1])
+           for k, v in cases.items() if k in ("on boundaries", "zeros and tiny", "outlier")}
+    big["all equal (multi-workgroup path)"] = torch.full((50000,), 0.37)
+    cases.update(big)
     for name, x in cases.items():
         try:
             fit = O.fit_scale(x, L, -1, 1)
