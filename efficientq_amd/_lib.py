@@ -79,6 +79,12 @@ class AdmmRunArgs(C.Structure):
                 ("stream_main", C.c_void_p), ("stream_loss", C.c_void_p), ("stream_side", C.c_void_p)]
 
 
+class ProfRecord(C.Structure):
+    """effq_prof_record of include/effq_hip.h."""
+    _fields_ = [("kind", C.c_int32), ("iter", C.c_int32), ("loss_kind", C.c_int32), ("c2", C.c_int32), ("n", C.c_int32),
+                ("geom", Geom), ("ms", C.c_float)]
+
+
 # name -> (restype, argtypes).  Must list every symbol include/effq_hip.h declares.
 SIGNATURES = {
     "effq_last_error": (C.c_char_p, []),
@@ -101,6 +107,12 @@ SIGNATURES = {
     "effq_fp_bucket_ws_bytes": (_SZ, [_SZ]),
     "effq_fixed_point_bucket": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _SZ, _P]),
     "effq_fp_check": (_I, [_P, _P, _P]),
+    "effq_conv_i8_pair_supported": (_I, [_GP, _I, _I]),
+    "conv3d_calib_step_i8_pair": (_I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _GP, _P, _I,
+                                      C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p), _P, _SZ, _P]),
+    "effq_prof_enable": (_I, [_I]),
+    "effq_prof_count": (_I, []),
+    "effq_prof_read": (_I, [_I, C.POINTER(ProfRecord)]),
     "effq_admm_num_inverses": (_I, [_D, _D, _I, _I]),
     "effq_admm_run": (_I, [C.POINTER(AdmmRunArgs)]),
     "effq_admm_select_best": (_I, [_P, _I, _P, _P, _SZ, _SZ, _P, _P, _P, _P]),

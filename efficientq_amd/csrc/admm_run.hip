@@ -10,6 +10,7 @@
 // b*, the scale state): slots are written once, so main never waits for loss.  The squared errors land in hist[i];
 // the best iterate is picked AFTER the loop (effq_admm_select_best), which is what lets a data-parallel caller
 // all-reduce the whole history with one collective per layer instead of one per iteration.
+#include <stdlib.h>
 #include <vector>
 #include "common.h"
 
@@ -20,6 +21,43 @@ int effq_project_dual_checked(const float* v, const float* wstar, const effq_fp_
 }
 
 namespace effq {
+
+// ---- sampling profiler of effq_admm_run (off by default): HIP-event pairs, on the stream the work is launched on,
+// around the ops of every `every`-th iteration.  bench.py reads them back after the timed region.
+struct ProfRec {
+  int kind, iter, loss_kind, c2, n;
+  effq_geom geom;
+  hipEvent_t e0, e1;
+};
+static thread_local std::vector<ProfRec> g_prof;
+static thread_local int g_prof_every = 0;
+enum { PROF_PROX = 1, PROF_FIXED_POINT = 2, PROF_PROJECT = 3, PROF_LOSS = 4, PROF_INVERSE = 5 };
+
+struct ProfScope {          // records e0 now, e1 at close()
+  bool on;
+  hipStream_t stream;
+  ProfRec rec;
+  ProfScope(bool enabled, int kind, int iter, const effq_admm_run_args* a, hipStream_t st) : on(enabled), stream(st) {
+    if (!on) return;
+    rec.kind = kind;
+    rec.iter = iter;
+    rec.loss_kind = a->loss_kind;
+    rec.c2 = a->c2;
+    rec.n = a->n;
+    rec.geom = a->geom;
+    if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(rec.e0, stream);
+  }
+  void close() {
+    if (!on) return;
+    (void)hipEventRecord(rec.e1, stream);
+    g_prof.push_back(rec);
+    on = false;
+  }
+};
 
 constexpr int ADMM_MAX_RHOS = 16;
 
@@ -116,13 +154,18 @@ int effq_admm_run(const effq_admm_run_args* a) {
     return EFFQ_ERR_ARG;
   }
   // weight-scale fixed point, by measured speed on MI355X (scripts/prof_fp.py, microseconds per call at 4 levels:
-  // 2048 values 16 all-values / 22 bucketed; 8192 36 / 28; 27648 84 / 37; 110592 120 / 77; 442368 146 / 107;
-  // 1.77 M 171 / 294 - random-address global atomics; at 256 levels the all-values kernels win at every size)
-  const bool bucket = a->fp_ws != nullptr && a->w_levels <= 16 && nw > 4096 && nw <= ((size_t)1 << 19);
+  // 2048 values 16 all-values / 22 bucketed; 8192 36 / 28; 27648 84 / 37; at 256 levels the all-values kernels win at
+  // every size).  The multi-workgroup bucketed path (110592: 120 / 77, 442368: 146 / 107 on Gaussian data) is NOT used
+  // here: inside ADMM the values cluster around the four levels, thousands of them share a bucket, and its global
+  // atomics serialise on those few addresses (154 us per count pass in situ, profiles/r02_*).
+  const bool bucket = a->fp_ws != nullptr && a->w_levels <= 16 && nw > 4096 && nw <= ((size_t)1 << 15);
   if (bucket && a->fp_ws_bytes < effq_fp_bucket_ws_bytes(nw)) {
     set_error("admm_run: fixed-point workspace %zu < %zu", a->fp_ws_bytes, effq_fp_bucket_ws_bytes(nw));
     return EFFQ_ERR_WORKSPACE;
   }
+  static const bool pair_off = getenv("EFFQ_I8_PAIR") != nullptr && atoi(getenv("EFFQ_I8_PAIR")) == 0;   // A/B switch
+  const bool pair = !pair_off && a->loss_kind == 1 &&
+                    effq_conv_i8_pair_supported(&a->geom, a->act_levels, a->w_levels) != 0;
   const RhoPlan plan = plan_rhos(a->rho, a->rho_max, a->iters, a->rho_period);
   EFFQ_CHECK_ARG(!plan.overflow);
   const int first = plan.shifted_first ? 1 : 0;
@@ -180,7 +223,11 @@ int effq_admm_run(const effq_admm_run_args* a) {
 
   ADMM_HIP(hipMemsetAsync(a->dual, 0, nw * sizeof(float), s_main));                 // dual <- 0 (EfficientQConv.py:40)
   // the inverse the first iterations need, on the main stream; the later ones on the side stream
-  ADMM_RC(effq_spd_inverse(a->A0, n, has_b, plan.rho[first], a->eta, a->ainv_pool, a->inv_ws, a->inv_ws_bytes, s_main));
+  {
+    ProfScope ps(g_prof_every > 0, PROF_INVERSE, -1, a, s_main);
+    ADMM_RC(effq_spd_inverse(a->A0, n, has_b, plan.rho[first], a->eta, a->ainv_pool, a->inv_ws, a->inv_ws_bytes, s_main));
+    ps.close();
+  }
   if (n_inv > 1) {
     if (fork_side) {
       ADMM_HIP(new_event(&ev_fork));
@@ -191,7 +238,9 @@ int effq_admm_run(const effq_admm_run_args* a) {
       float* dst = a->ainv_pool + (size_t)(r - first) * ainv_elems;
       void* ws = fork_side ? a->inv_ws_side : a->inv_ws;
       const size_t wsb = fork_side ? a->inv_ws_side_bytes : a->inv_ws_bytes;
+      ProfScope ps(g_prof_every > 0, PROF_INVERSE, -1 - r, a, s_side);
       ADMM_RC(effq_spd_inverse(a->A0, n, has_b, plan.rho[r], a->eta, dst, ws, wsb, s_side));
+      ps.close();
       if (fork_side) {
         ADMM_HIP(new_event(&ev_inv[r]));
         ADMM_HIP(hipEventRecord(ev_inv[r], s_side));
@@ -222,6 +271,8 @@ int effq_admm_run(const effq_admm_run_args* a) {
     float* bstar = has_b ? a->b_ring + (size_t)i * c2 : nullptr;
     effq_fp_state* st = a->state_ring + i;
     // ---- the chain (main stream) ----
+    const bool prof = g_prof_every > 0 && !use_shift && (i % g_prof_every) == g_prof_every / 2;
+    ProfScope p_prox(prof, PROF_PROX, i, a, s_main);
     if (use_shift)
       ADMM_RC(effq_prox_solve_shifted(a->B0, a->ainv_pool, a->W0, a->b0, G_prev, a->dual, c2, n, has_b, rho, a->eta,
                                       plan.rho[1], shift_terms(rho, a->eta, plan.rho[1]), a->wstar, bstar, a->prox_ws,
@@ -229,6 +280,8 @@ int effq_admm_run(const effq_admm_run_args* a) {
     else
       ADMM_RC(effq_prox_solve(a->B0, Ainv, a->W0, a->b0, G_prev, a->dual, c2, n, has_b, rho, a->eta, a->wstar, bstar,
                               a->prox_ws, a->prox_ws_bytes, s_main));
+    p_prox.close();
+    ProfScope p_fp(prof, PROF_FIXED_POINT, i, a, s_main);
     if (bucket)
       ADMM_RC(effq_fixed_point_bucket(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
                                       a->fp_ws, a->fp_ws_bytes, s_main));
@@ -238,16 +291,34 @@ int effq_admm_run(const effq_admm_run_args* a) {
     else
       ADMM_RC(effq_fixed_point_coop(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
                                     a->red_ws, s_main));
+    p_fp.close();
+    ProfScope p_pr(prof, PROF_PROJECT, i, a, s_main);
     ADMM_RC(effq_project_dual_checked(a->v, a->wstar, st, a->w_levels, G, a->dual, dual_div, Gq, nw, a->err_flag,
                                       s_main));
-    // ---- the loss of this iterate (loss stream) ----
+    p_pr.close();
+    // ---- the loss of this iterate (loss stream); 32 -> 32 layers evaluate two iterates per pass ----
+    const bool last = (i == a->iters - 1);
+    if (pair && (i & 1) == 0 && !last) {
+      if (i % a->rho_period == 0) rho = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
+      continue;                               // evaluated together with iterate i + 1
+    }
     if (fork_loss) {
       hipEvent_t e = ev_main[i % EV_POOL];
       ADMM_HIP(hipEventRecord(e, s_main));
       ADMM_HIP(hipStreamWaitEvent(s_loss, e, 0));
     }
     double* sq = a->hist + 2 * (size_t)i;
-    if (a->loss_kind == 1)
+    ProfScope p_loss(prof || (pair && g_prof_every > 0 && ((i - 1) % g_prof_every) == g_prof_every / 2), PROF_LOSS, i, a,
+                     s_loss);
+    if (pair && (i & 1) == 1) {
+      const int8_t* gq2[2] = {Gq - nw, Gq};
+      const float* b2[2] = {has_b ? bstar - c2 : nullptr, bstar};
+      const effq_fp_state* st2[2] = {st - 1, st};
+      double* sq2[2] = {sq - 2, sq};
+      p_loss.rec.loss_kind = 3;               // (profiler: the paired form)
+      ADMM_RC(conv3d_calib_step_i8_pair(a->xidx, gq2, b2, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, st2,
+                                        a->w_levels, sq2, a->conv_ws, a->conv_ws_bytes, s_loss));
+    } else if (a->loss_kind == 1)
       ADMM_RC(conv3d_calib_step_i8(a->xidx, Gq, bstar, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, st,
                                    a->w_levels, sq, a->conv_ws, a->conv_ws_bytes, s_loss));
     else if (a->loss_kind == 2)
@@ -256,6 +327,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
     else
       ADMM_RC(conv3d_quant_calib_step(a->xq, G, bstar, a->y_fp, nullptr, &a->geom, nullptr, 0, sq, nullptr, a->conv_ws,
                                       a->conv_ws_bytes, s_loss));   // unweighted MSE (quirk Q5)
+    p_loss.close();
     if (i % a->rho_period == 0) rho = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
   }
   // join: everything the caller reads next (hist, rings) is ordered on the main stream
@@ -272,6 +344,33 @@ int effq_admm_run(const effq_admm_run_args* a) {
   destroy_events();
 #undef ADMM_HIP
 #undef ADMM_RC
+  return EFFQ_OK;
+}
+
+int effq_prof_enable(int every) {
+  for (ProfRec& r : g_prof) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  g_prof_every = every > 0 ? every : 0;
+  return EFFQ_OK;
+}
+
+int effq_prof_count(void) { return (int)g_prof.size(); }
+
+int effq_prof_read(int i, effq_prof_record* out) {
+  EFFQ_CHECK_ARG(out != nullptr && i >= 0 && i < (int)g_prof.size());
+  const ProfRec& r = g_prof[(size_t)i];
+  float ms = 0.0f;
+  EFFQ_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));      // the caller has synchronised the device
+  out->kind = r.kind;
+  out->iter = r.iter;
+  out->loss_kind = r.loss_kind;
+  out->c2 = r.c2;
+  out->n = r.n;
+  out->geom = r.geom;
+  out->ms = ms;
   return EFFQ_OK;
 }
 

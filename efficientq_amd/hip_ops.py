@@ -579,6 +579,23 @@ class HipOps:
                                             _ptr(ws), ws.numel(), self.stream), "conv3d_calib_step_i8")
         return sqerr
 
+    def conv_step_i8_pair(self, xidx, Gq2, bias2, geom: Geom, y_ndhwc, act_alpha, act_levels: int, w_state2,
+                          w_levels: int, sqerr2):
+        """Exact-integer loss of TWO iterates in one pass over x and y (conv3d_calib_step_i8_pair).  Gq2, bias2,
+        w_state2, sqerr2: pairs of tensors (bias2 entries may both be None)."""
+        if xidx.dtype != torch.uint8 or any(t.dtype != torch.int8 for t in Gq2):
+            raise _lib.EffqError("conv_step_i8_pair wants uint8 level ids and int8 weight numerators")
+        for q, b in zip(Gq2, bias2):
+            _check_shapes(geom, xidx, q, b, y_ndhwc)
+        al = self._f32(act_alpha.reshape(1))
+        ws = self._workspace("conv_i8", self.lib.effq_conv_i8_ws_bytes(C.byref(geom)))
+        arr = lambda ts: (C.c_void_p * 2)(*[None if t is None else t.data_ptr() for t in ts])
+        check(self.lib.conv3d_calib_step_i8_pair(_ptr(xidx), arr(Gq2), arr(bias2), _ptr(self._f32(y_ndhwc)),
+                                                 C.byref(geom), _ptr(al), int(act_levels), arr(w_state2), int(w_levels),
+                                                 arr(sqerr2), _ptr(ws), ws.numel(), self.stream),
+              "conv3d_calib_step_i8_pair")
+        return sqerr2
+
     def admm_keep_best(self, sqerr, best, it: int, G, b, best_G, best_b):
         if best.numel() < 4:
             raise _lib.EffqError("admm_keep_best: best_dev holds 4 doubles (loss, iteration, ticket, spare)")

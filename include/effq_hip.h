@@ -228,6 +228,16 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
                          const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, void* ws,
                          size_t ws_bytes, void* stream);
 
+/* TWO iterates in one pass (32 -> 32 channels: that layer shape is bound by the stream of targets, and the loss of an
+ * iterate is only needed when the best one is picked after the loop): Gq[2], bias[2] (both NULL or both given),
+ * w_state_dev[2], sqerr_out[2] are host arrays of two device pointers.  Each result is bit-identical to the single
+ * call.  ws: effq_conv_i8_ws_bytes(geom) (it covers both forms). */
+int effq_conv_i8_pair_supported(const effq_geom* g, int act_levels, int w_levels);
+int conv3d_calib_step_i8_pair(const uint8_t* xidx_ndhwc, const int8_t* const* Gq, const float* const* bias,
+                              const float* y_fp, const effq_geom* g, const float* act_alpha_dev, int act_levels,
+                              const effq_fp_state* const* w_state_dev, int w_levels, double* const* sqerr_out, void* ws,
+                              size_t ws_bytes, void* stream);
+
 /* The same exact-integer loss for the layers the tiled kernels above do not take: few taps*channels
  * (KD*KH*KW*C1 <= 256 with C1 == 4 or C1 % 16 == 0: the first conv, the 1x1x1 convs, the classifier), any
  * stride/padding, and up to 256 levels on either side (q_first/q_last = 256 in the reference's recipes).
@@ -311,6 +321,21 @@ int effq_admm_run(const effq_admm_run_args* a);
  * copies its G / b* out of the rings; best_out[0] = its loss sum, best_out[1] = its index (as a double). */
 int effq_admm_select_best(const double* hist, int iters, const float* G_ring, const float* b_ring, size_t nw, size_t nb,
                           float* best_G, float* best_b, double* best_out, void* stream);
+
+/* ---- measurement aid: sampling profiler of effq_admm_run (off by default, per host thread) ---------------------
+ * effq_prof_enable(every > 0): from now on every `every`-th iteration of effq_admm_run brackets its ops with HIP-event
+ * pairs recorded on the stream the op is launched on; effq_prof_enable(0) stops and drops the records.  After the
+ * caller has synchronised the device, effq_prof_read(i) returns record i: kind 1 prox solve, 2 weight-scale fixed point,
+ * 3 projection + dual update, 4 loss evaluation (conv + squared error, with its weight pack), 5 inverse of A(rho)
+ * (iter < 0); ms = elapsed time between the two events. */
+typedef struct effq_prof_record {
+  int32_t kind, iter, loss_kind, c2, n;
+  effq_geom geom;
+  float ms;
+} effq_prof_record;
+int effq_prof_enable(int every);
+int effq_prof_count(void);
+int effq_prof_read(int i, effq_prof_record* out);
 
 /* ---- f2: bit-packed storage of level ids ---------------------------------------------------
  * The reference stores one uint8 per weight (store_int_weight, PTQConv.py:125-152); these pack the level ids

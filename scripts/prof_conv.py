@@ -25,8 +25,11 @@ Gq = torch.empty(w.shape, dtype=torch.int8, device=dev)
 st_w = ops.new_fp_state()
 ops.weight_fixed_point(w, dual, v, 4, st_w)
 ops.admm_project_dual(v, w, st_w, 4, G, dual, 1.0, Gq)
+Gq2 = [Gq, Gq.clone()]; st2 = [st_w, st_w.clone()]; sq2 = [sq, sq.clone()]
 def step():
-    if mode.startswith("i8"):
+    if mode == "i8_32p":
+        ops.conv_step_i8_pair(xidx, Gq2, [b, b], geom, y, alpha, 4, st2, 4, sq2)
+    elif mode.startswith("i8"):
         ops.conv_step_i8(xidx, Gq, b, geom, y, alpha, 4, st_w, 4, sq)
     else:
         ops.conv_step(xq, G, b, geom, y, None, sqerr=sq)
@@ -38,6 +41,7 @@ for _ in range(n):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
 fl = 2.0 * C * C * 27 * N * S ** 3
-by = (4.0 * C + (1.0 if mode.startswith("i8") else 4.0) * C) * N * S ** 3
+by = (4.0 * C + (1.0 if mode.startswith("i8") else 4.0) * C) * N * S ** 3 * (2 if mode == "i8_32p" else 1)
+fl *= (2 if mode == "i8_32p" else 1)
 print(f"{mode}: sqerr {sq.tolist()[0]:.6e}  avg {ms:.4f} ms  {fl / ms / 1e9:.2f} TFLOP/s ({fl / ms / 1e9 / 157.3 * 100:.1f}% f32 MFMA)  "
       f"{by / ms / 1e6:.0f} GB/s algorithmic ({by / ms / 1e6 / 8000 * 100:.1f}% of 8 TB/s)")

@@ -427,6 +427,55 @@ def test_exact_int_conv_step_equals_fp32_path(ops, c1, c2, La, Lw, sp):
     assert sq8b.cpu().tolist() == s8
 
 
+@pytest.mark.parametrize("sp,La,Lw,with_bias", [((16, 8, 8), 4, 4, True), ((5, 6, 9), 4, 4, True), ((17, 4, 8), 16, 16, False),
+                                                  ((33, 7, 10), 4, 4, True)])
+def test_paired_exact_int_conv_equals_two_single_passes(ops, sp, La, Lw, with_bias):
+    """conv3d_calib_step_i8_pair: the losses of two iterates from ONE pass over x and y (32 -> 32 channels) equal two
+    single passes (same integer sums per iterate; the squared errors are added in another order, and the single-pass
+    kernel for tile-divisible volumes adds them in fp32 within a tile: compared to 1e-6) and the fp64 value of the
+    integer model to 1e-6; ragged volumes included (extent not a multiple of the 16 x 4 x 8 tile)."""
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(sum(sp) + La)
+    N, c = 2, 32
+    x = torch.relu(torch.randn(N, *sp, c, generator=gen))
+    geom = make_geom((N, c, *sp), c, 3, 1, 1)
+    assert ops.lib.effq_conv_i8_pair_supported(geom, La, Lw)
+    a_act, _, st_a = ops.fit_scale(dev(x), La, 0.0, 1.0)
+    _, _, xidx = ops.quant_dequant_f64path(dev(x), st_a, La, 0.0, 1.0, want_idx=True)
+    alpha_act = torch.tensor(a_act, dtype=torch.float32, device="cuda:0")
+    y = dev(torch.randn(N, *sp, c, generator=gen))
+    Gqs, sts, bs = [], [], []
+    for it in range(2):
+        wst = dev(torch.randn(c, c, 3, 3, 3, generator=gen) * (0.05 + 0.02 * it))
+        dual, v, G = torch.zeros_like(wst), torch.empty_like(wst), torch.empty_like(wst)
+        st_w = ops.new_fp_state()
+        ops.weight_fixed_point(wst, dual, v, Lw, st_w)
+        Gq = torch.empty(wst.shape, dtype=torch.int8, device="cuda:0")
+        ops.admm_project_dual(v, wst, st_w, Lw, G, dual, 1.0, Gq)
+        Gqs.append(Gq)
+        sts.append(st_w)
+        bs.append(dev(torch.randn(c, generator=gen) * 0.1) if with_bias else None)
+    single = []
+    for it in range(2):
+        sq = torch.zeros(2, dtype=torch.float64, device="cuda:0")
+        ops.conv_step_i8(xidx, Gqs[it], bs[it], geom, y, alpha_act, La, sts[it], Lw, sq)
+        single.append(sq.cpu().tolist())
+    sq2 = [torch.zeros(2, dtype=torch.float64, device="cuda:0") for _ in range(2)]
+    ops.conv_step_i8_pair(xidx, Gqs, bs, geom, y, alpha_act, La, sts, Lw, sq2)
+    for it in range(2):
+        got = sq2[it].cpu().tolist()
+        assert got[0] == got[1]
+        assert abs(got[0] - single[it][0]) <= 1e-6 * single[it][0], (it, got, single[it])
+        out = torch.nn.functional.conv3d(xidx.cpu().permute(0, 4, 1, 2, 3).double(), Gqs[it].cpu().double(), None, 1, 1)
+        sc = float(np.float32(a_act)) * float(np.float32(ops.read_fp_state(sts[it])[0])) / ((La - 1) * (Lw - 1))
+        bb = bs[it].cpu().double().view(1, -1, 1, 1, 1) if with_bias else 0.0
+        ref = ((out * sc + bb - y.cpu().permute(0, 4, 1, 2, 3).double()) ** 2).sum().item()
+        assert abs(got[0] - ref) <= 1e-6 * ref
+    again = [torch.zeros(2, dtype=torch.float64, device="cuda:0") for _ in range(2)]
+    ops.conv_step_i8_pair(xidx, Gqs, bs, geom, y, alpha_act, La, sts, Lw, again)
+    assert [t.cpu().tolist() for t in again] == [t.cpu().tolist() for t in sq2]          # deterministic
+
+
 @pytest.mark.parametrize("c1,c2,k,s,p,La,Lw,sp", [
     (4, 32, 3, 2, 1, 256, 256, (12, 10, 14)),     # the first conv of the BraTS net (q_first = 256)
     (32, 3, 1, 1, 0, 256, 256, (6, 7, 9)),        # the classifier (q_last = 256)
