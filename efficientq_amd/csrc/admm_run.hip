@@ -153,18 +153,22 @@ int effq_admm_run(const effq_admm_run_args* a) {
     set_error("admm_run: %zu weights exceed the single-launch fixed points", nw);
     return EFFQ_ERR_ARG;
   }
-  // weight-scale fixed point, by measured speed on MI355X (scripts/prof_fp.py, microseconds per call at 4 levels:
-  // 2048 values 16 all-values / 22 bucketed; 8192 36 / 28; 27648 84 / 37; at 256 levels the all-values kernels win at
-  // every size).  The multi-workgroup bucketed path (110592: 120 / 77, 442368: 146 / 107 on Gaussian data) is NOT used
-  // here: inside ADMM the values cluster around the four levels, thousands of them share a bucket, and its global
-  // atomics serialise on those few addresses (154 us per count pass in situ, profiles/r02_*).
-  const bool bucket = a->fp_ws != nullptr && a->w_levels <= 16 && nw > 4096 && nw <= ((size_t)1 << 15);
+  // weight-scale fixed point, by measured speed on MI355X (scripts/prof_fp.py, microseconds per call at 4 levels,
+  // all-values kernel / bucketed: 2048 values 16 / 22; 8192 36 / 28; 27648 84 / 37; 110592 125 / 51; 442368 143 / 65;
+  // 1.77 M 171 / 163 alone but slower inside the loop (1261 vs 1224 ms per calibration); at 256 levels the all-values
+  // kernels win at every size)
+  static const size_t bucket_max = getenv("EFFQ_FP_BUCKET_MAX") ? (size_t)atoll(getenv("EFFQ_FP_BUCKET_MAX"))
+                                                                : ((size_t)1 << 19);          // tuning aid
+  const bool bucket = a->fp_ws != nullptr && a->w_levels <= 16 && nw > 4096 && nw <= bucket_max;
   if (bucket && a->fp_ws_bytes < effq_fp_bucket_ws_bytes(nw)) {
     set_error("admm_run: fixed-point workspace %zu < %zu", a->fp_ws_bytes, effq_fp_bucket_ws_bytes(nw));
     return EFFQ_ERR_WORKSPACE;
   }
-  static const bool pair_off = getenv("EFFQ_I8_PAIR") != nullptr && atoi(getenv("EFFQ_I8_PAIR")) == 0;   // A/B switch
-  const bool pair = !pair_off && a->loss_kind == 1 &&
+  // two iterates per pass over x and y (conv3d_calib_step_i8_pair): 17 % less conv time per iterate alone, but its
+  // one-workgroup-per-CU footprint keeps the chain kernels of the next iterations off the CUs (1240 vs 1224 ms per
+  // calibration): opt-in
+  static const bool pair_on = getenv("EFFQ_I8_PAIR") != nullptr && atoi(getenv("EFFQ_I8_PAIR")) != 0;
+  const bool pair = pair_on && a->loss_kind == 1 &&
                     effq_conv_i8_pair_supported(&a->geom, a->act_levels, a->w_levels) != 0;
   const RhoPlan plan = plan_rhos(a->rho, a->rho_max, a->iters, a->rho_period);
   EFFQ_CHECK_ARG(!plan.overflow);

@@ -514,8 +514,8 @@ __global__ __launch_bounds__(FPS2_T) void k_fps(const float* __restrict__ a, con
 // ---- path G: large tensors, four launches ------------------------------------------------------------------------------------
 // k_fpg_sum   : v = a + b2 -> v_out, |v| partials and max|v| per workgroup; the last workgroup to finish (ticket) adds
 //               them in workgroup order: sum|v| (deterministic) and the bucket range R = max|v| (nothing is clamped).
-// k_fpg_count : counts the values into the buckets with global atomics (the returned count is the value's rank in its
-//               bucket) and adds their integer units.
+// k_fpg_count : counts the values into the buckets (workgroup-private LDS histograms merged with one global atomic per
+//               non-empty bucket) and adds their integer units; leaves every value's rank inside its bucket.
 // k_fpg_scan  : exclusive prefixes of counts and sums, counters cleared for the next call.
 // k_fpg_scatter_iter : every workgroup regroups its values (slot = bucket offset + rank); the last one iterates.
 struct FpgHeader {          // first 256 bytes of the workspace
@@ -647,33 +647,58 @@ __global__ __launch_bounds__(FPG_T) void k_fpg_sum(const float* __restrict__ a, 
   }
 }
 
-__global__ __launch_bounds__(FPG_T) void k_fpg_count(const float* __restrict__ src, size_t n, int B, FpgWs w) {
+// Counting with workgroup-private histograms: inside ADMM the values cluster around the few quantisation levels, so
+// thousands of them share a bucket and global atomics on those few addresses serialise (154 us per pass in situ with
+// one global atomic per value).  Each workgroup counts its slice of FPG_SLICE values in LDS (count + integer sum per
+// bucket, LDS atomics; the returned count is the value's rank among the slice's values of that bucket), then adds its
+// non-empty buckets to the global tables with ONE atomic each (consecutive addresses: coalesced wave instructions);
+// the value returned by that add is where the slice's values start inside the global bucket.
+constexpr int FPG_B = 8192;                   // buckets of the multi-workgroup path (count + sum tables: 96 KB of LDS)
+constexpr int FPG_CT = 1024;                  // threads of the count kernel
+constexpr int FPG_SLICE = FPG_CT * FPG_EPT;   // values per workgroup
+__global__ __launch_bounds__(FPG_CT) void k_fpg_count(const float* __restrict__ src, size_t n, FpgWs w) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* isum_l = reinterpret_cast<unsigned long long*>(smem_raw);     // [FPG_B]
+  unsigned* cnt_l = reinterpret_cast<unsigned*>(isum_l + FPG_B);                     // [FPG_B]
   const int tid = threadIdx.x;
-  const FpbGeo g = fpb_geo(w.hdr->range, B);
-  // three sweeps so that the loads, then the atomics, are in flight together (a returning atomic takes a microsecond
-  // or two: one value after the other would serialise 2 x FPG_EPT of them)
+  const FpbGeo g = fpb_geo(w.hdr->range, FPG_B);
   float vv[FPG_EPT];
   unsigned rk[FPG_EPT];
-  const size_t base = (size_t)blockIdx.x * (FPG_T * FPG_EPT) + tid;
+  int bk[FPG_EPT];
+  const size_t base = (size_t)blockIdx.x * FPG_SLICE + tid;
 #pragma unroll
   for (int e = 0; e < FPG_EPT; ++e) {
-    const size_t i = base + (size_t)e * FPG_T;
+    const size_t i = base + (size_t)e * FPG_CT;
     vv[e] = src[(i < n) ? i : (n - 1)];
   }
+  for (int b = tid; b < FPG_B; b += FPG_CT) {
+    cnt_l[b] = 0u;
+    isum_l[b] = 0ull;
+  }
+  __syncthreads();
 #pragma unroll
   for (int e = 0; e < FPG_EPT; ++e) {
-    const size_t i = base + (size_t)e * FPG_T;
+    const size_t i = base + (size_t)e * FPG_CT;
+    bk[e] = fpb_bucket(vv[e], g);
     rk[e] = 0u;
     if (i < n) {
-      const int b = fpb_bucket(vv[e], g);
-      rk[e] = atomicAdd(&w.cnt[b], 1u);
-      atomicAdd(&w.isum[b], (unsigned long long)fpb_units(vv[e], b, g));
+      rk[e] = atomicAdd(&cnt_l[bk[e]], 1u);
+      atomicAdd(&isum_l[bk[e]], (unsigned long long)fpb_units(vv[e], bk[e], g));
     }
   }
+  __syncthreads();
+  for (int b = tid; b < FPG_B; b += FPG_CT) {
+    const unsigned c = cnt_l[b];
+    if (c != 0u) {
+      cnt_l[b] = atomicAdd(&w.cnt[b], c);       // start of this slice's values inside the global bucket
+      atomicAdd(&w.isum[b], isum_l[b]);
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int e = 0; e < FPG_EPT; ++e) {
-    const size_t i = base + (size_t)e * FPG_T;
-    if (i < n) w.rank[i] = rk[e];
+    const size_t i = base + (size_t)e * FPG_CT;
+    if (i < n) w.rank[i] = cnt_l[bk[e]] + rk[e];
   }
 }
 
@@ -824,14 +849,22 @@ int effq_fixed_point_bucket(const float* a, const float* b, float* v_out, size_t
       return EFFQ_ERR_WORKSPACE;
     }
     const FpgWs w = fpg_carve(ws, n);
-    // ~27 values per bucket on average
-    const int B = (n <= ((size_t)1 << 17)) ? 4096 : (n <= ((size_t)1 << 19)) ? 16384 : FPG_MAXB;
+    const int B = FPG_B;
     const size_t blocks = (n + (size_t)FPG_T * FPG_EPT - 1) / ((size_t)FPG_T * FPG_EPT);
     EFFQ_CHECK_ARG(blocks <= FPG_MAXBLK);
     // (without b the values are already in place: the sum pass then only reads)
     const float* src = (v_out != nullptr) ? v_out : a;
     hipLaunchKernelGGL(k_fpg_sum, dim3((unsigned)blocks), dim3(FPG_T), 0, st, a, b, v_out, n, w);
-    hipLaunchKernelGGL(k_fpg_count, dim3((unsigned)blocks), dim3(FPG_T), 0, st, src, n, B, w);
+    {
+      static bool attr_set2 = false;
+      const int lds = (int)((sizeof(unsigned long long) + sizeof(unsigned)) * FPG_B);
+      if (!attr_set2) {
+        EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpg_count), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set2 = true;
+      }
+      const size_t cblocks = (n + FPG_SLICE - 1) / FPG_SLICE;
+      hipLaunchKernelGGL(k_fpg_count, dim3((unsigned)cblocks), dim3(FPG_CT), lds, st, src, n, w);
+    }
     hipLaunchKernelGGL(k_fpg_scan, dim3((unsigned)(B / FPG_SEG)), dim3(FPG_SEG), 0, st, B, w);
     hipLaunchKernelGGL(k_fpg_scatter_iter, dim3((unsigned)blocks), dim3(FPG_T), 0, st, src, n, B, w, state_dev, lo, hi, d,
                        levels, tol, max_iter);
