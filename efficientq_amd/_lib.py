@@ -110,6 +110,10 @@ SIGNATURES = {
     "effq_conv_i8_pair_supported": (_I, [_GP, _I, _I]),
     "conv3d_calib_step_i8_pair": (_I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _GP, _P, _I,
                                       C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p), _P, _SZ, _P]),
+    "effq_gram_packed_elems": (_SZ, [_I, _I]),
+    "effq_gram_pack": (_I, [_P, _P, _I, _I, _P, _P]),
+    "effq_gram_unpack": (_I, [_P, _I, _I, _P, _P, _P]),
+    "effq_act_quant_backward": (_I, [_P, _P, _I, _P, _P, _P, _SZ, _P, _P]),
     "effq_prof_enable": (_I, [_I]),
     "effq_prof_count": (_I, []),
     "effq_prof_read": (_I, [_I, C.POINTER(ProfRecord)]),

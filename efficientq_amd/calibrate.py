@@ -230,9 +230,19 @@ def get_calibration_data(args, data_cube):
 
 
 # ---- the calibration run ---------------------------------------------------------------------------
+# hooks.py:5-6 stores `o.detach().cpu()`.  With the model on a GPU - the reference's intended device - that is a COPY,
+# taken before the next block's in-place ReLU (factoryQ.py:76-77) rewrites the conv's output.  With the model on the CPU
+# `.cpu()` returns the tensor itself, and the targets of the 11 convs (of 22, BraTS net) that feed an in-place ReLU
+# silently become relu(y): the reference then calibrates those layers against the wrong target (first-layer loss 0.125
+# instead of 1.3e-4 on the BraTS net, FP-vs-Q agreement 0.93 instead of 0.99).  Default here: the copy (GPU behaviour);
+# ALIAS_FP_TARGETS / EFFQ_ALIAS_FP_TARGETS=1 reproduces a CPU run of the reference (what the g6 fixtures hold).
+import os as _os
+ALIAS_FP_TARGETS = _os.environ.get("EFFQ_ALIAS_FP_TARGETS", "0") == "1"
+
+
 def forward_hook(m, i, o):
-    """FP target capture; stays on the device (the reference moves it to the host, hooks.py:5-6)."""
-    m.output_fp = o.detach()
+    """FP target capture; stays on the device."""
+    m.output_fp = o.detach() if ALIAS_FP_TARGETS else o.detach().clone()
 
 
 def _sync(device):

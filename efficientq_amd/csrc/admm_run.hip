@@ -99,6 +99,39 @@ static int shift_terms(double rho, double eta, double rho_inv) {
   return t < 2 ? 2 : (t > 64 ? 64 : t);
 }
 
+// ---- Gram system packed for the data-parallel exchange: upper triangle of A0 (row-major, n(n+1)/2) then B0 (c2 x n) ----
+__global__ __launch_bounds__(256) void k_gram_pack(const float* __restrict__ A0, const float* __restrict__ B0, int n, int c2,
+                                                   float* __restrict__ buf) {
+  const size_t tri = (size_t)n * (n + 1) / 2, nb = (size_t)c2 * n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)n * n + nb; e += stride) {
+    if (e < (size_t)n * n) {
+      const int i = (int)(e / n), j = (int)(e % n);
+      if (j >= i) buf[(size_t)i * n - (size_t)i * (i - 1) / 2 + (j - i)] = A0[e];
+    } else {
+      buf[tri + (e - (size_t)n * n)] = B0[e - (size_t)n * n];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_gram_unpack(const float* __restrict__ buf, int n, int c2, float* __restrict__ A0,
+                                                     float* __restrict__ B0) {
+  const size_t tri = (size_t)n * (n + 1) / 2, nb = (size_t)c2 * n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)n * n + nb; e += stride) {
+    if (e < (size_t)n * n) {
+      int i = (int)(e / n), j = (int)(e % n);
+      if (j < i) {              // mirror: A0 is exactly symmetric
+        const int t = i;
+        i = j;
+        j = t;
+      }
+      A0[e] = buf[(size_t)i * n - (size_t)i * (i - 1) / 2 + (j - i)];
+    } else {
+      B0[e - (size_t)n * n] = buf[tri + (e - (size_t)n * n)];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_select_best(const double* __restrict__ hist, int iters,
                                                      const float* __restrict__ G_ring, const float* __restrict__ b_ring,
                                                      size_t nw, size_t nb, float* __restrict__ best_G,
@@ -348,6 +381,28 @@ int effq_admm_run(const effq_admm_run_args* a) {
   destroy_events();
 #undef ADMM_HIP
 #undef ADMM_RC
+  return EFFQ_OK;
+}
+
+size_t effq_gram_packed_elems(int n, int c2) {
+  return (n > 0 && c2 > 0) ? (size_t)n * (n + 1) / 2 + (size_t)c2 * n : 0;
+}
+
+int effq_gram_pack(const float* A0, const float* B0, int n, int c2, float* buf, void* stream) {
+  EFFQ_CHECK_ARG(A0 && B0 && buf && n > 0 && c2 > 0);
+  size_t blocks = ((size_t)n * n + (size_t)c2 * n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_gram_pack, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), A0, B0, n, c2, buf);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_gram_unpack(const float* buf, int n, int c2, float* A0, float* B0, void* stream) {
+  EFFQ_CHECK_ARG(A0 && B0 && buf && n > 0 && c2 > 0);
+  size_t blocks = ((size_t)n * n + (size_t)c2 * n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_gram_unpack, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), buf, n, c2, A0, B0);
+  EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }
 

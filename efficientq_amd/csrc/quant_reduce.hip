@@ -555,6 +555,32 @@ __global__ __launch_bounds__(TPB) void k_keep_best(const double* __restrict__ sq
   }
 }
 
+// ---- backward of PTQConv._quantize_act with the straight-through estimator (row f3) ------------------------------------
+// q = discretize(x / alpha, L, 0, 1) * alpha (PTQConv.py:114-116), round with identity gradient (layer_helper.py:13-22),
+// clamp with torch's gradient mask (1 where lo <= u <= hi, bounds included).  With u = x / alpha, r = discretize(u):
+//   dq/dx = mask,    dq/dalpha = r - mask * u          =>   gx = gq * mask,   galpha = sum gq * (r - mask * u)
+// (the chain rule autograd applies to the reference's five elementwise ops, collected into one pass).
+__global__ __launch_bounds__(TPB) void k_act_quant_bwd(const float* __restrict__ x, const float* __restrict__ alpha_dev,
+                                                       float lo, float hi, float d, const float* __restrict__ gq,
+                                                       float* __restrict__ gx, size_t n, double* partials,
+                                                       unsigned int* ticket, double* galpha_out) {
+  __shared__ double smem[16];
+  __shared__ int s_last;
+  const float alpha = *alpha_dev;
+  double acc[1] = {0.0};
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float u = x[i] / alpha;
+    const float c = fminf(fmaxf(u, lo), hi);
+    const float r = rintf((c - lo) / d) * d + lo;
+    const float m = (u >= lo && u <= hi) ? 1.0f : 0.0f;
+    const float g = gq[i];
+    if (gx != nullptr) gx[i] = g * m;
+    acc[0] += (double)(g * (r - m * u));
+  }
+  grid_sum_finish<1>(acc, partials, ticket, galpha_out, smem, &s_last);
+}
+
 __global__ __launch_bounds__(TPB) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v, float lr, float b1,
                                               float b2, float eps, float bc1, float bc2, size_t n) {
@@ -833,6 +859,17 @@ int effq_admm_keep_best(const double* sqerr_dev, double* best_dev, int iter, con
   EFFQ_CHECK_ARG((b == nullptr) == (best_b == nullptr));
   hipLaunchKernelGGL(k_keep_best, dim3(stream_grid(nw)), dim3(TPB), 0, as_stream(stream), sqerr_dev, best_dev, iter,
                      G, b, best_G, best_b, nw, nb);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_act_quant_backward(const float* x, const float* alpha_dev, int levels, const float* gq, float* gx_out,
+                            double* galpha_out, size_t n, void* ws, void* stream) {
+  EFFQ_CHECK_ARG(x && alpha_dev && gq && galpha_out && ws && n > 0 && levels >= 2);
+  RedWs r = red_ws(ws);
+  const float d = (float)(1.0 / (double)(levels - 1));
+  hipLaunchKernelGGL(k_act_quant_bwd, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), x, alpha_dev, 0.0f, 1.0f, d,
+                     gq, gx_out, n, r.partials, r.ticket, galpha_out);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

@@ -347,6 +347,15 @@ class HipOps:
                                           ws.numel(), self.stream), "effq_gram_accum_i8")
         return A0, B0
 
+    def gram_reduce(self, A0: torch.Tensor, B0: torch.Tensor, reducer):
+        """Data-parallel SUM of a layer's Gram system as ONE message: upper triangle of A0 + B0 (effq_gram_pack)."""
+        n, c2 = int(A0.shape[0]), int(B0.shape[0])
+        buf = torch.empty(self.lib.effq_gram_packed_elems(n, c2), dtype=torch.float32, device=self.device)
+        check(self.lib.effq_gram_pack(_ptr(A0), _ptr(B0), n, c2, _ptr(buf), self.stream), "effq_gram_pack")
+        reducer(buf)
+        check(self.lib.effq_gram_unpack(_ptr(buf), n, c2, _ptr(A0), _ptr(B0), self.stream), "effq_gram_unpack")
+        return A0, B0
+
     # -- f2: bit-packed level ids -------------------------------------------------------------
     @staticmethod
     def storage_bits(levels: int) -> int:
@@ -595,6 +604,22 @@ class HipOps:
                                                  arr(sqerr2), _ptr(ws), ws.numel(), self.stream),
               "conv3d_calib_step_i8_pair")
         return sqerr2
+
+    # -- f3: gradients of the activation quantiser, Adam ----------------------------------------------------
+    def act_quant_backward(self, x: torch.Tensor, alpha: torch.Tensor, levels: int, gq: torch.Tensor, want_gx=True):
+        """(gx, galpha[device double]) of q = discretize(x/alpha, L, 0, 1)*alpha given gq (effq_act_quant_backward)."""
+        x, gq = self._f32(x), self._f32(gq)
+        a = self._f32(alpha.reshape(1))
+        gx = torch.empty_like(x) if want_gx else None
+        ga = torch.empty(1, dtype=torch.float64, device=self.device)
+        check(self.lib.effq_act_quant_backward(_ptr(x), _ptr(a), int(levels), _ptr(gq), _ptr(gx), _ptr(ga), x.numel(),
+                                               _ptr(self._red_ws), self.stream), "effq_act_quant_backward")
+        return gx, ga
+
+    def adam_step(self, p, g, m, v, lr: float, t: int, b1=0.9, b2=0.999, eps=1e-8):
+        """torch.optim.Adam step in place on flat fp32 tensors (effq_adam_step)."""
+        check(self.lib.effq_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), lr, b1, b2, eps, int(t), p.numel(),
+                                      self.stream), "effq_adam_step")
 
     def admm_keep_best(self, sqerr, best, it: int, G, b, best_G, best_b):
         if best.numel() < 4:

@@ -40,7 +40,9 @@ class SumReducer:
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist = dist
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # EFFQ_DP_FORCE=1: run the collectives even on one rank (exercises the RCCL path on a single GPU)
+        force = _os.environ.get("EFFQ_DP_FORCE", "0") == "1"
+        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.group = group
 
     def __call__(self, t: torch.Tensor) -> torch.Tensor:
@@ -57,6 +59,33 @@ class SumReducer:
 
     def __bool__(self):
         return self.on
+
+
+class _QuantConvFn(torch.autograd.Function):
+    """Quantised forward of a PTQConv with gradients for tune_activation_range (ptqer.py:238-272): the forward is the
+    fused act-quant conv kernel; the backward is the same conv kernel on the output gradient (flipped, transposed
+    weights) followed by the straight-through backward of the activation quantiser.  Weights take no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, mod):
+        ctx.mod = mod
+        ctx.save_for_backward(x, alpha)
+        # (a fresh tensor, not the permuted view _conv returns: the next block's in-place ReLU writes into it)
+        return mod._conv(x, mod.q_act).clone(memory_format=torch.preserve_format)
+
+    @staticmethod
+    def backward(ctx, g):
+        mod = ctx.mod
+        x, alpha = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0]
+        if not need_x and not mod.q_act:
+            return None, None, None
+        gq = mod._dgrad(g)
+        if not mod.q_act:
+            return gq, None, None
+        ops = get_ops(g.device)
+        gx, ga = ops.act_quant_backward(to_ndhwc(x.detach()), alpha.detach(), mod.qlvl_act, to_ndhwc(gq), want_gx=need_x)
+        return (from_ndhwc(gx) if need_x else None), ga.to(alpha.dtype).reshape(alpha.shape), None
 
 
 class PTQConv(nn.Conv3d):
@@ -121,6 +150,19 @@ class PTQConv(nn.Conv3d):
                                act_levels=self.qlvl_act if quantize_act else 0, want_out=True)
         return from_ndhwc(out)
 
+    def _dgrad(self, g):
+        """Gradient of the conv w.r.t. its input: the conv kernel on g with flipped, transposed weights (stride 1)."""
+        if self.stride != (1, 1, 1):
+            raise NotImplementedError("input gradient of a strided conv is not needed on the calibrated path")
+        ops = get_ops(g.device)
+        key = (self.weight.data_ptr(), self.weight._version)
+        if getattr(self, "_wt_key", None) != key:
+            self._wt = self.weight.data.flip(2, 3, 4).transpose(0, 1).contiguous()
+            self._wt_key = key
+        geom = make_geom(g.shape, self.in_channels, self.kernel_size, self.stride, self.padding)
+        out, _ = ops.conv_step(to_ndhwc(g.detach()), self._wt, None, geom, want_out=True)
+        return from_ndhwc(out)
+
     def _quantize_act(self, x):
         """discretize(x/alpha_act, L, 0, 1) * alpha_act in fp32 (PTQConv.py:114-116)."""
         ops = get_ops(x.device)
@@ -134,10 +176,23 @@ class PTQConv(nn.Conv3d):
         """PTQConv.py:74-78."""
         ops = get_ops(x.device)
         xn = to_ndhwc(x.detach())
-        a, _, st = ops.fit_scale(xn, self.qlvl_act, 0.0, 1.0, reducer=SumReducer() or None)
+        red = SumReducer()
+        if self.qlvl_act < 2:
+            # "W,-1" layers (full-precision activations, quirk Q14) still pass through here in the init pass: with
+            # num_lvl = -1 project_by_iter's loop never runs (max_iter = -100), so a = mean|x|, and discretize works with
+            # delta = 1/(-2): values land on {0, 0.5, 1} - the arithmetic of 3 levels (layer_helper.py:25-37,50-66)
+            s0 = ops.abs_sum(xn)
+            if red:
+                red(s0)
+            st = ops.new_fp_state()
+            st[0] = s0[0] / s0[1]
+            a, levels = st[0].item(), 3
+        else:
+            a, _, st = ops.fit_scale(xn, self.qlvl_act, 0.0, 1.0, reducer=red or None)
+            levels = self.qlvl_act
         self.alpha_act.data = torch.tensor(a, device=x.device)
         self._act_inited = True
-        y, _, _ = ops.quant_dequant_f64path(xn, st, self.qlvl_act, 0.0, 1.0)
+        y, _, _ = ops.quant_dequant_f64path(xn, st, levels, 0.0, 1.0)
         return from_ndhwc(y)
 
     def ptq(self, x):
@@ -187,6 +242,8 @@ class PTQConv(nn.Conv3d):
             self.ptq(x)
             return self._conv(x, self.q_act)
         if self._quantized:
+            if torch.is_grad_enabled() and (self.alpha_act.requires_grad or x.requires_grad):
+                return _QuantConvFn.apply(x, self.alpha_act, self)      # tune_activation_range (row f3)
             return self._conv(x, self.q_act)
         if self._init_act:
             qact = self.init_alpha_act(x)
@@ -283,8 +340,12 @@ class EfficientQConvHIP(PTQConv):
             A0, B0 = ops.gram_i8(xidx, att_cls, yn, geom, has_b, self.alpha_act.data, self.qlvl_act)
         else:
             A0, B0 = ops.gram(xq, att, yn, geom, has_b)
-        red(A0)
-        red(B0)
+        if red:                      # one message per layer: upper triangle of A0 + B0
+            if hasattr(ops, "gram_reduce"):
+                ops.gram_reduce(A0, B0, red)
+            else:
+                red(A0)
+                red(B0)
 
         # The 200 iterations (:99-144) are enqueued by ONE library call (effq_admm_run): the serial chain prox ->
         # scale fixed point -> projection/dual on this stream, the loss of iteration i (conv + MSE, used only to pick

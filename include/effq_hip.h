@@ -251,7 +251,15 @@ int conv3d_calib_step_i8s(const uint8_t* xidx_ndhwc, const int8_t* Gq, const flo
                           const effq_fp_state* w_state_dev, int w_levels, int prepare, double* sqerr_out,
                           void* ws, size_t ws_bytes, void* stream);
 
-/* ---- f3 (next row): Adam step for tune_activation_range (ptqer.py:238-272) ---- */
+/* ---- f3: tune_activation_range (ptqer.py:238-272) - Adam on every alpha_act, end-to-end MSE, STE through discretize ----
+ * Backward of q = discretize(x / alpha, L, 0, 1) * alpha (PTQConv.py:114-116; round with identity gradient,
+ * layer_helper.py:13-22; clamp with torch's inclusive mask) given gq = dLoss/dq:
+ *   gx_out = gq * mask (may be NULL),  *galpha_out (device double) = sum gq * (r - mask * x / alpha).
+ * ws: the reduction workspace (effq_reduce_ws_bytes()).  The input gradient of the conv itself is the conv entry point
+ * applied to the output gradient with flipped, transposed weights (stride 1). */
+int effq_act_quant_backward(const float* x, const float* alpha_dev, int levels, const float* gq, float* gx_out,
+                            double* galpha_out, size_t n, void* ws, void* stream);
+/* torch.optim.Adam step (no weight decay, no amsgrad) on n parameters; t = step number starting at 1. */
 int effq_adam_step(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
                    int t, size_t n, void* stream);
 
@@ -321,6 +329,14 @@ int effq_admm_run(const effq_admm_run_args* a);
  * copies its G / b* out of the rings; best_out[0] = its loss sum, best_out[1] = its index (as a double). */
 int effq_admm_select_best(const double* hist, int iters, const float* G_ring, const float* b_ring, size_t nw, size_t nb,
                           float* best_G, float* best_b, double* best_out, void* stream);
+
+/* ---- the Gram system as ONE data-parallel message ------------------------------------------------------------------
+ * A0 is symmetric: a rank's partial sums travel as [upper triangle of A0, row-major: n(n+1)/2 floats | B0: c2*n floats]
+ * (effq_gram_packed_elems), one all-reduce per layer instead of two and half the bytes of the full matrix
+ * (solver.py:302-312 sums the per-sample contributions the same way).  unpack mirrors the triangle back. */
+size_t effq_gram_packed_elems(int n, int c2);
+int effq_gram_pack(const float* A0, const float* B0, int n, int c2, float* buf, void* stream);
+int effq_gram_unpack(const float* buf, int n, int c2, float* A0, float* B0, void* stream);
 
 /* ---- measurement aid: sampling profiler of effq_admm_run (off by default, per host thread) ---------------------
  * effq_prof_enable(every > 0): from now on every `every`-th iteration of effq_admm_run brackets its ops with HIP-event

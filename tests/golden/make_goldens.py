@@ -313,8 +313,19 @@ def randomise(model, seed):
                 m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
 
 
-def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False):
+def _copying_hook(m, i, o):
+    """hooks.py:5-6 as it behaves with the model on a GPU (the reference's intended device, entrance.py --device): there
+    `o.detach().cpu()` is a COPY taken before the next block's in-place ReLU (factoryQ.py:76-77) rewrites the conv's
+    output.  On the CPU - the only device this container has - `.cpu()` returns the tensor itself, and the targets of the
+    convs that feed an in-place ReLU silently become relu(y).  The g6c fixtures are generated with the copy restored."""
+    m.output_fp = o.detach().clone()
+
+
+def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_targets=False):
     root = "/tmp/effq_gold"
+    orig_hook = ptqer.forward_hook
+    if copy_targets:
+        ptqer.forward_hook = _copying_hook
     os.makedirs(root + "/snap", exist_ok=True)
     if task == "lits":
         args = tiny_args("lits", L, S, 1, 3)
@@ -371,6 +382,7 @@ def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False):
         ptqer.do_ptq(args, mc, cube, tester, root + "/snap")
     finally:
         ptqer.set_mask, ptqer.extract_nii = orig_set_mask, orig_extract
+        ptqer.forward_hook = orig_hook
     with open(root + "/snap/layer_loss.txt") as f:
         ll = f.read().strip().split("\n")
     with open(root + "/snap/class_voxel_nums.txt") as f:
@@ -543,3 +555,53 @@ if __name__ == "__main__":
         g6("lits", 4, 32, "g6_tiny_lits_L4")
     if "g6b" in which:
         g6("brats", 4, 64, "g6_tiny_brats_L4")
+
+
+# ---------------------------------------------------------------- G12 tune_activation_range (row f3)
+def g12():
+    """The reference's tune_activation_range (ptqer.py:238-272; dead code there, run in isolation here) on the tiny
+    lits net: alpha_act initialised by the reference's own init pass (need_init=True), then 50 Adam steps."""
+    root = "/tmp/effq_gold"
+    os.makedirs(root, exist_ok=True)
+    S, L = 16, 4
+    args = tiny_args("lits", L, S, 1, 3)
+    QConv, Qinfo, kwQ = definer.get_conv_class(args)
+    mc, _ = definer.get_model_cube(args, QConv, kwQ)
+    model = mc["model"]
+    randomise(model, 707)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model.eval()
+    fold_bn.search_fold_and_remove_bn(model)
+    vols = torch.randn(2, 1, S, S, S, generator=torch.Generator().manual_seed(12))
+    ptqer.set_fp(model)
+    with torch.no_grad():
+        output_fp = model(vols).detach()
+    losses = ptqer.tune_activation_range(model, output_fp, vols, max_iter=50, need_init=True)
+    names, alphas = [], []
+    for n, m in model.named_modules():
+        if isinstance(m, PTQConv):
+            names.append(n)
+            alphas.append(float(m.alpha_act.data))
+    # the alphas right after the init pass: run it again on a fresh copy
+    mc2, _ = definer.get_model_cube(args, QConv, kwQ)
+    m2 = mc2["model"]
+    m2.load_state_dict(sd0)
+    m2.eval()
+    fold_bn.search_fold_and_remove_bn(m2)
+    ptqer.set_init_alpha(m2)
+    with torch.no_grad():
+        m2(vols)
+    init = [float(m.alpha_act.data) for n, m in m2.named_modules() if isinstance(m, PTQConv)]
+    out = {f"sd0/{k}": v for k, v in sd0.items()}
+    out.update(vols_seed=np.int64(12), meta=np.array([S, L]), loss_all=np.array(losses, dtype=np.float64),
+               alpha_final=np.array(alphas, dtype=np.float64), alpha_init=np.array(init, dtype=np.float64),
+               layer_names=np.array(names))
+    print("g12 loss first/last", losses[0], losses[-1], "alphas", [f"{a:.4f}" for a in alphas])
+    save("g12_tune_act.npz", **out)
+
+
+if __name__ == "__main__" and "g12" in sys.argv[1:]:
+    g12()
+if __name__ == "__main__" and "g6c" in sys.argv[1:]:
+    g6("lits", 4, 32, "g6c_tiny_lits_L4", copy_targets=True)
+    g6("brats", 4, 64, "g6c_tiny_brats_L4", copy_targets=True)

@@ -1,0 +1,174 @@
+"""BASELINE.json's configurations at their real network geometry (-m gpu): the BraTS net of config 2 / 3 at 4/4 and 16/16
+levels on full 4x128^3 volumes, the LiTS net of config 4 on 1x160^3 volumes (widths to 512, n = 13825), the tiny net of
+config 1 at 256/256 levels - each through calibrate_model - and the solver at the system sizes those networks reach
+(n = 6913, 13825).  Volumes per GPU are cut to 2 to keep the suite short; everything per-layer (shapes, system sizes,
+kernels chosen) is what the full configurations run."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import effq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(net, L, seed=0):
+    from efficientq_amd import calibrate as K, config as Cf, synth
+    args = Cf.make_args(net, L, L)
+    QConv, _, kwQ = Cf.get_conv_class(args)
+    model = Cf.get_model_cube(args, QConv, kwQ)[0]["model"]
+    synth.randomise_network(model, seed)
+    model.eval()
+    K.search_fold_and_remove_bn(model)
+    K.set_name(model)
+    return args, model
+
+
+def _qlayers(model):
+    from efficientq_amd.qconv import PTQConv
+    return [(n, m) for n, m in model.named_modules() if isinstance(m, PTQConv)]
+
+
+def _check_calibrated(model, res, n_layers, task, agree_floor):
+    losses = np.array([float(l.split(":")[1]) for l in res["layer_loss"]])
+    assert len(losses) == n_layers and np.all(np.isfinite(losses)) and np.all(losses >= 0)
+    for name, m in _qlayers(model):
+        w = m.weight.data
+        distinct = torch.unique(w).numel()
+        assert distinct <= m.qlvl_w, (name, distinct, m.qlvl_w)          # weights sit on the level grid
+        # weight = (BEST iterate's scale) * level while alpha_w is the LAST iterate's scale (quirk Q6; the two differ by
+        # tens of percent on some layers): the grid is checked against the weight's own scale
+        lv = (w / w.abs().max() + 1) * (m.qlvl_w - 1) / 2
+        assert (lv - torch.round(lv)).abs().max() <= 2e-3, name
+        assert torch.isfinite(m.bias.data).all() and m.alpha_w.item() > 0
+        if m.q_act:
+            assert m.alpha_act.item() > 0
+    if task == "brats":
+        agree = ((res["output_q"][-1] > 0) == (res["output_fp"][-1] > 0)).float().mean().item()
+    else:
+        agree = (res["output_q"][-1].argmax(1) == res["output_fp"][-1].argmax(1)).float().mean().item()
+    assert agree >= agree_floor, agree
+    return losses, agree
+
+
+def test_config2_brats_net_4_levels_first_layer_vs_oracle():
+    """configs[1] geometry: 22 quantised convs, widths 32..256, 4x128^3 volumes, 4/4 levels (first / last layer 256
+    weight levels on FP input).  The first layer sees identical inputs on both sides: its layer_loss must equal the CPU
+    oracle's (which reproduces the reference bit for bit) to north_star's 1e-3."""
+    from efficientq_amd import calibrate as K, config as Cf, synth
+    args, model = _build(Cf.BRATS_NET, 4)
+    pristine = {k: v.clone() for k, v in model.state_dict().items()}
+    vols = synth.calib_batch("brats", range(2), 128)
+    model.to(DEV)
+    res = K.calibrate_model(model, vols.to(DEV), "brats", args.init_stride)
+    losses, agree = _check_calibrated(model, res, 22, "brats", 0.85)
+    name0, _ = _qlayers(model)[0]
+    w0, b0 = pristine[name0 + ".weight"], pristine[name0 + ".bias"]
+    y = torch.nn.functional.conv3d(vols, w0, b0, 2, 1)
+    pyr = [m.cpu() for m in res["pyramid"]]
+    want = O.calibrate_layer(vols, y, w0, b0, 2, 1, qlvl_w=256, qlvl_act=-1, q_act=False, mask_pyramid=pyr)
+    assert abs(losses[0] - want.layer_loss) <= 1e-3 * want.layer_loss, (losses[0], want.layer_loss)
+    print(f"config 2 geometry: first layer_loss hip {losses[0]:.6e} oracle {want.layer_loss:.6e}; FP-vs-Q agreement {agree:.4f}")
+
+
+def test_fp_targets_are_snapshots_taken_before_the_in_place_relu():
+    """hooks.py:5-6 copies a conv's FP output (to the host) the moment it is produced; half of the convs of the net feed
+    an in-place ReLU (factoryQ.py:76-77), which must not reach the stored target."""
+    from efficientq_amd import calibrate as K, config as Cf, synth
+    args, model = _build(Cf.BRATS_NET, 4)
+    vols = synth.calib_batch("brats", range(1), 64).to(DEV)
+    model.to(DEV)
+    layers = _qlayers(model)
+    handles = [m.register_forward_hook(K.forward_hook) for _, m in layers]
+    K.set_fp(model)
+    with torch.no_grad():
+        model(vols)
+    for h in handles:
+        h.remove()
+    name0, c0 = layers[0]
+    want = torch.nn.functional.conv3d(vols, c0.weight.data, c0.bias.data, c0.stride, c0.padding)
+    assert (c0.output_fp - want).abs().max() <= 1e-4 * want.abs().max()
+    negative = [n for n, m in layers if m.output_fp.min().item() < 0]
+    assert len(negative) == len(layers), set(n for n, _ in layers) - set(negative)     # no target is a ReLU output
+
+
+def test_config3_brats_net_16_levels():
+    """configs[2] arithmetic (16/16 levels: 176-iteration activation fixed points, 57-iteration weight fixed points,
+    16-level exact-integer convs and Gram systems) on the BraTS net."""
+    from efficientq_amd import calibrate as K, config as Cf, synth
+    args, model = _build(Cf.BRATS_NET, 16)
+    vols = synth.calib_batch("brats", range(2), 128)
+    model.to(DEV)
+    res = K.calibrate_model(model, vols.to(DEV), "brats", args.init_stride)
+    _, agree = _check_calibrated(model, res, 22, "brats", 0.95)
+    used_int = [m.last_trace["exact_int"] for _, m in _qlayers(model)]
+    # every layer with quantised input runs its losses on the i8 matrix cores (all but the first conv and the classifier)
+    assert sum(used_int) >= 20, [(n, m.last_trace["exact_int"]) for n, m in _qlayers(model)]
+    print(f"config 3 arithmetic: FP-vs-Q agreement {agree:.4f}")
+
+
+def test_config4_lits_net_widths_to_512():
+    """configs[3] geometry: the LiTS net (28 quantised convs, widths 32..512, init_stride 2,2,1) on 1x160^3 volumes:
+    n = 13825 Gram systems / inverses and 7.08 M-weight projections."""
+    from efficientq_amd import calibrate as K, config as Cf, synth
+    args, model = _build(Cf.LITS_NET, 4)
+    vols = synth.calib_batch("lits", range(2), 160)
+    model.to(DEV)
+    res = K.calibrate_model(model, vols.to(DEV), "lits", args.init_stride)
+    _, agree = _check_calibrated(model, res, 28, "lits", 0.80)
+    widest = max(m.in_channels for _, m in _qlayers(model))
+    assert widest == 512
+    print(f"config 4 geometry: FP-vs-Q agreement {agree:.4f}")
+
+
+def test_config1_tiny_net_256_levels():
+    """configs[0]: tiny UResQ (width 8,16,8) on 2 x 1x64^3 volumes at 256/256 levels (the 2500-iteration activation
+    fixed points, 256-level short-K exact-integer convs)."""
+    from efficientq_amd import calibrate as K, config as Cf
+    args, model = _build(Cf.TINY_NET, 256)
+    vols = torch.randn(2, 1, 64, 64, 64, generator=torch.Generator().manual_seed(1))
+    model.to(DEV)
+    res = K.calibrate_model(model, vols.to(DEV), "lits", args.init_stride)
+    _, agree = _check_calibrated(model, res, 10, "lits", 0.97)
+    print(f"config 1: FP-vs-Q agreement {agree:.4f}")
+
+
+@pytest.mark.parametrize("n,c2", [(6913, 256), (13825, 512)])
+def test_solver_at_the_largest_system_sizes(n, c2):
+    """effq_spd_inverse / effq_prox_solve at n = 6913 (BraTS 256 channels) and 13825 (LiTS 512) against fp64 on the
+    device (fp64 products as the checker): normwise residual of A^-1 at fp32 rounding level, exactly symmetric; residual
+    of w* to 2e-5 (the reference's own fp32 LU sits at 9e-5)."""
+    from efficientq_amd.hip_ops import get_ops
+    ops = get_ops(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    X = torch.randn(n, 2 * n, device=DEV, generator=gen)
+    X[-1] = 1.0                                          # the bias row of the patch matrix
+    A0 = (2.0 * (X @ X.T)).contiguous()
+    del X
+    rho, eta = 10.0 * n, 1.0 * n
+    Ainv = ops.spd_inverse(A0, True, rho, eta)
+    d = torch.full((n,), rho + eta, dtype=torch.float64, device=DEV)
+    d[-1] = eta
+    A64 = A0.double() + torch.diag(d)
+    X64 = Ainv[:, :n].double()
+    assert torch.equal(Ainv[:, :n], Ainv[:, :n].T)
+    # normwise residual of the inverse (fp64 products on the device are the checker; no LAPACK call at this size)
+    R = A64 @ X64
+    R.diagonal().sub_(1.0)
+    res_inv = (R.norm() / (A64.norm() * X64.norm())).item()
+    del R
+    W0 = torch.randn(c2, n - 1, device=DEV, generator=gen) * 0.05
+    b0 = torch.randn(c2, device=DEV, generator=gen) * 0.1
+    B0 = torch.randn(c2, n, device=DEV, generator=gen) * float(n)
+    G = W0 + 0.01 * torch.randn(c2, n - 1, device=DEV, generator=gen)
+    dual = 0.01 * torch.randn(c2, n - 1, device=DEV, generator=gen)
+    wstar, bstar = torch.empty_like(W0), torch.empty_like(b0)
+    ops.prox_solve(B0, Ainv, W0, b0, G, dual, rho, eta, wstar, bstar)
+    B = B0.double() + eta * torch.cat([W0, b0[:, None]], 1).double()
+    B[:, : n - 1] += rho * (G - dual).double()
+    got = torch.cat([wstar, bstar[:, None]], 1).double()
+    res_sol = ((got @ A64 - B).norm() / B.norm()).item()
+    print(f"n={n}: inverse residual |A X - I|_F / (|A|_F |X|_F) = {res_inv:.2e}; solve residual |W A - B|_F / |B|_F = {res_sol:.2e}")
+    assert res_inv <= 1e-7          # fp32 rounding of an fp64 inverse: 6e-8 per entry
+    assert res_sol <= 2e-5          # fp32 GEMM over K = n (the reference's fp32 LU sits at 9e-5)

@@ -557,6 +557,29 @@ def test_cooperative_weight_fixed_point_matches_oracle(ops, n, L):
     assert ops.read_fp_state(st2) == (alpha, iters, done)
 
 
+@pytest.mark.parametrize("n,c2", [(33, 3), (109, 32), (865, 32)])
+def test_gram_system_packs_into_one_message_and_back(ops, n, c2):
+    """effq_gram_pack / effq_gram_unpack: upper triangle of A0 + B0, exact round trip; summing two packed partial systems
+    equals packing their sum (what the data-parallel all-reduce does)."""
+    gen = torch.Generator().manual_seed(n)
+    mk = lambda: (lambda m: (m + m.T).contiguous())(torch.randn(n, n, generator=gen))
+    A1, A2 = dev(mk()), dev(mk())
+    B1, B2 = dev(torch.randn(c2, n, generator=gen)), dev(torch.randn(c2, n, generator=gen))
+    bufs = []
+    for A, B in ((A1, B1), (A2, B2)):
+        buf = torch.empty(ops.lib.effq_gram_packed_elems(n, c2), dtype=torch.float32, device="cuda:0")
+        from efficientq_amd.hip_ops import check, _ptr
+        check(ops.lib.effq_gram_pack(_ptr(A), _ptr(B), n, c2, _ptr(buf), ops.stream), "pack")
+        bufs.append(buf)
+    assert bufs[0].numel() == n * (n + 1) // 2 + c2 * n
+    iu = torch.triu_indices(n, n)
+    assert torch.equal(bufs[0][: n * (n + 1) // 2].cpu(), A1.cpu()[iu[0], iu[1]])
+    A, B = A1.clone(), B1.clone()
+    got = ops.gram_reduce(A, B, lambda t: t.add_(bufs[1]))          # "all-reduce" over two ranks
+    assert torch.equal(got[0], A1 + A2) and torch.equal(got[1], B1 + B2)
+    assert torch.equal(got[0], got[0].T)
+
+
 # ------------------------------------------------------------------ a2: bucketed single-workgroup fixed point
 def _run_bucket(ops, a, b, L, lo=-1.0, hi=1.0):
     v = torch.empty(a.numel(), device="cuda:0") if b is not None else None

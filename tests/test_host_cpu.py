@@ -190,6 +190,9 @@ def test_product_ptq_on_oracle_backend_matches_reference(gold, monkeypatch, tag)
 def _run_tiny(task, fname, gold, monkeypatch):
     from efficientq_amd import calibrate as K
     cpu_backend.install(monkeypatch)
+    # g6_*: the reference run on the CPU, where its hook's `.cpu()` aliases the conv output and the next in-place ReLU
+    # overwrites half of the targets; g6c_*: the same run with the copy a GPU run makes (make_goldens._copying_hook)
+    monkeypatch.setattr(K, "ALIAS_FP_TARGETS", not fname.startswith("g6c"))
     g = gold(fname)
     args, model, _ = _tiny(task)
     model.load_state_dict({k[4:]: T(g[k]) for k in g.files if k.startswith("sd0/")}, strict=False)
@@ -208,7 +211,7 @@ def _run_tiny(task, fname, gold, monkeypatch):
     return g, model, res
 
 
-@pytest.mark.parametrize("task,fname", [("brats", "g6_tiny_brats_L4.npz")])
+@pytest.mark.parametrize("task,fname", [("brats", "g6_tiny_brats_L4.npz"), ("brats", "g6c_tiny_brats_L4.npz")])
 def test_whole_calibration_on_oracle_backend_matches_reference(gold, monkeypatch, task, fname):
     g, model, res = _run_tiny(task, fname, gold, monkeypatch)
     names = [l.split(":")[0].strip() for l in res["layer_loss"]]
@@ -223,8 +226,10 @@ def test_whole_calibration_on_oracle_backend_matches_reference(gold, monkeypatch
     # differ and their losses drift at the percent level, in both directions (hard parts).
     want = g["layer_loss"]
     assert np.all(np.abs(got[:3] - want[:3]) <= 1e-5 * want[:3]), (got, want)
-    assert np.all(np.abs(got - want) <= 5e-2 * want), (got, want)
-    assert abs(got.sum() - want.sum()) <= 3e-2 * want.sum()
+    # (the copy-semantics run drifts a little more on its late layers: 9 % on one of them, towards either side)
+    drift, total = (1.2e-1, 5e-2) if fname.startswith("g6c") else (5e-2, 3e-2)
+    assert np.all(np.abs(got - want) <= drift * want), (got, want)
+    assert abs(got.sum() - want.sum()) <= total * want.sum()
     sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4), slice(None, None, 4))
     assert torch.allclose(res["output_fp"][-1][sub], T(g["output_fp_sub"]), atol=1e-5)
     oq, oq_ref = res["output_q"][-1][sub], T(g["output_q_sub"])

@@ -98,16 +98,24 @@ def test_wide_layer_calibration_within_reference_self_spread(gold, tag):
         sub = int(g[f"{tag}_fwd_sub"])
         d_out = _rel_mse(out[:, :, ::sub, ::sub, ::sub], T(g[f"{tag}_t{nt}_fwd_q"]))
         rep[nt] = (d_ll, d_best, d_idx, d_out)
-        assert d_ll <= max(1e-3, 3 * sp["layer_loss"]), (d_ll, sp)
-        assert d_best <= max(1e-3, 3 * sp["best_mse"]), (d_best, sp)
+        # plateau values: the (att-weighted) layer_loss and the (unweighted) best iterate loss measure the same plateau;
+        # bar = north_star's 1e-3 or 3x the larger of the two distances the reference keeps from itself
+        plateau = max(sp["layer_loss"], sp["best_mse"])
+        assert d_ll <= max(1e-3, 3 * plateau), (d_ll, sp)
+        assert d_best <= max(1e-3, 3 * plateau), (d_best, sp)
         assert d_idx <= 2 * sp["idx_mismatch"], (d_idx, sp)
         assert d_out <= max(1e-3, 2 * sp["out_rel_mse"]), (d_out, sp)      # the assertion r1 had dropped
     print(f"{tag}: reference self-spread {sp}; hip vs t1/t8 (layer_loss, best, idx, out rel-MSE) = {rep}")
 
 
-@pytest.mark.parametrize("task,fname", [("brats", "g6_tiny_brats_L4.npz"), ("lits", "g6_tiny_lits_L4.npz")])
-def test_whole_calibration_matches_reference(gold, task, fname):
+@pytest.mark.parametrize("task,fname", [("brats", "g6_tiny_brats_L4.npz"), ("lits", "g6_tiny_lits_L4.npz"),
+                                        ("brats", "g6c_tiny_brats_L4.npz"), ("lits", "g6c_tiny_lits_L4.npz")])
+def test_whole_calibration_matches_reference(gold, monkeypatch, task, fname):
+    """Whole do_ptq window against the reference, in both of its behaviours: g6_* = as it runs on the CPU (the hook's
+    `.cpu()` aliases the conv output there, so the targets of the convs feeding an in-place ReLU are overwritten);
+    g6c_* = with the copy a GPU run makes (the product's default; tests/golden/make_goldens.py:_copying_hook)."""
     from efficientq_amd import calibrate as K
+    monkeypatch.setattr(K, "ALIAS_FP_TARGETS", not fname.startswith("g6c"))
     g = gold(fname)
     args, model, _ = _tiny(task)
     model.load_state_dict({k[4:]: T(g[k]) for k in g.files if k.startswith("sd0/")}, strict=False)
@@ -227,6 +235,63 @@ def test_data_parallel_two_ranks_on_one_gpu_matches_single_rank(tmp_path):
     assert abs(a[0] - b[0]) <= 1e-6 * b[0], (a, b)      # first layer: identical inputs, sums re-associated only
     assert np.all(np.abs(a - b) <= 1e-1 * b), (a, b)    # later layers: plateau drift
     assert abs(a.sum() - b.sum()) <= 3e-2 * b.sum()
+
+
+def test_collectives_on_rccl_with_one_rank_are_the_identity(tmp_path):
+    """The data-parallel code path on the REAL backend ("nccl" = RCCL), one rank: every collective the sharded
+    calibration issues runs on RCCL on the stream the product uses it on; the result is bit-identical to the run
+    without collectives, and a layer costs a bounded number of them (statistics 3, activation fixed point ~45 at 4
+    levels, Gram 1, loss history 1, final loss 1)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "nccl1.pt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dp_worker_nccl.py"), out], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = torch.load(out)
+    for k in d["plain"]["sd"]:
+        assert torch.equal(d["forced"]["sd"][k], d["plain"]["sd"][k]), k
+    assert d["forced"]["loss"] == d["plain"]["loss"] and d["forced"]["nums"] == d["plain"]["nums"]
+    layers = len(d["plain"]["loss"])
+    # <= ~60 collectives per layer at 4 levels (the 200 per-iteration losses travel as ONE message), + the class census
+    assert 0 < d["forced"]["collectives"] <= 70 * layers + 8, (d["forced"]["collectives"], layers)
+
+
+def test_tune_activation_range_matches_reference(gold):
+    """Row f3: the reference's tune_activation_range (ptqer.py:238-272) run in isolation on the tiny lits net (G12: init
+    pass + 50 Adam steps at lr 5e-4) against the product (conv / input-gradient / quantiser-backward / Adam on the HIP
+    library).  alpha_act after the init pass: 1e-6; loss history and final alpha_act: 2e-3 (a step moves an alpha by
+    <= 5e-4 whatever the size of its gradient, so fp32 summation-order differences in a gradient near zero can cost a
+    few steps' worth of drift)."""
+    from efficientq_amd import calibrate as K
+    from efficientq_amd.qconv import PTQConv
+    from efficientq_amd.tune import tune_activation_range
+    g = gold("g12_tune_act.npz")
+    args, model, _ = _tiny("lits")
+    model.load_state_dict({k[4:]: T(g[k]) for k in g.files if k.startswith("sd0/")}, strict=False)
+    model.eval()
+    K.search_fold_and_remove_bn(model)
+    model.to(DEV)
+    S = int(g["meta"][0])
+    vols = torch.randn(2, 1, S, S, S, generator=torch.Generator().manual_seed(int(g["vols_seed"]))).to(DEV)
+    K.set_fp(model)
+    with torch.no_grad():
+        output_fp = model(vols).detach()
+    mods = [(n, m) for n, m in model.named_modules() if isinstance(m, PTQConv)]
+    assert [n for n, _ in mods] == g["layer_names"].tolist()
+    K.set_init_alpha(model)
+    with torch.no_grad():
+        model(vols)
+    init = np.array([m.alpha_act.item() for _, m in mods])
+    assert np.all(np.abs(init - g["alpha_init"]) <= 1e-6 * g["alpha_init"]), (init, g["alpha_init"])
+    losses = tune_activation_range(model, output_fp, vols, max_iter=50, need_init=True)
+    want = g["loss_all"]
+    assert len(losses) == 50
+    assert np.all(np.abs(np.array(losses) - want) <= 2e-3 * want), (losses[:5], want[:5], losses[-3:], want[-3:])
+    final = np.array([m.alpha_act.item() for _, m in mods])
+    assert np.all(np.abs(final - g["alpha_final"]) <= 2e-3 * g["alpha_final"]), (final, g["alpha_final"])
+    assert losses[-1] < losses[0]
 
 
 def test_cli_ptq_mission_writes_reference_artifacts(tmp_path):
