@@ -37,7 +37,7 @@ class Geom(C.Structure):
 
 
 class FpState(C.Structure):
-    """effq_fp_state of include/effq_hip.h (48 bytes)."""
+    """effq_fp_state of include/effq_hip.h (40 bytes)."""
     _fields_ = [("alpha", C.c_double), ("alpha_prev", C.c_double), ("sums", C.c_double * 2),
                 ("iters", C.c_int32), ("done", C.c_int32)]
 
@@ -114,6 +114,8 @@ SIGNATURES = {
     "effq_gram_pack": (_I, [_P, _P, _I, _I, _P, _P]),
     "effq_gram_unpack": (_I, [_P, _I, _I, _P, _P, _P]),
     "effq_act_quant_backward": (_I, [_P, _P, _I, _P, _P, _P, _SZ, _P, _P]),
+    "effq_att_classes_ws_bytes": (_SZ, []),
+    "effq_att_classes": (_I, [_P, _LL, _P, _P, _P, C.POINTER(C.c_int32), _P, _P]),
     "effq_prof_enable": (_I, [_I]),
     "effq_prof_count": (_I, []),
     "effq_prof_read": (_I, [_I, C.POINTER(ProfRecord)]),

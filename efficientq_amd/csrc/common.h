@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/effq_hip.h"
 
@@ -30,6 +31,20 @@ void set_error(const char* fmt, ...);
 #define EFFQ_LAUNCH_CHECK() EFFQ_HIP(hipGetLastError())
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Profiling ablations ("run the kernel without its MFMA loop / its loads ...") exist only in builds made with
+// -DEFFQ_ABLATE (make ABLATE=1): in the shipped library EFFQ_DBG(p) is the constant 0 and the branches fold away, and no
+// environment variable is read on a launch path.
+#ifdef EFFQ_ABLATE
+#define EFFQ_DBG(p) ((p).debug)
+static inline int effq_ablate_env(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+#else
+#define EFFQ_DBG(p) 0
+static inline int effq_ablate_env(const char*) { return 0; }
+#endif
 
 // ---- reduction workspace -------------------------------------------------------------
 // [0, RED_MAX_BLOCKS*RED_SLOTS) doubles of per-block partials, then one uint32 ticket.

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
     // fetched before the current step's MFMAs: one step has only 4*NT MFMAs, too few to hide an L2 round trip
     {
       const int nq = p.cslab >> 3;
-      const int total = (p.debug == 1) ? 0 : p.KD * p.KH * p.KW * nq;
+      const int total = (EFFQ_DBG(p) == 1) ? 0 : p.KD * p.KH * p.KW * nq;
       const float* abase = lds + hv * CS + 4 * lh;
       const float* wbase = p.wp + ((size_t)(((slab * p.cslab) >> 2) + lh) * p.c2p + ch0 + li) * 4;
       const size_t wtap = (size_t)(p.c1p >> 2) * p.c2p * 4;       // floats between taps
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
       if (HAS_Y) load_y(tn, ynext);       // consumed only after a slab-0 stage (ycur = ynext there)
     }
 
-    const int ntap = (p.debug == 1) ? 0 : 27;
+    const int ntap = (EFFQ_DBG(p) == 1) ? 0 : 27;
 #pragma unroll 1
     for (int tap = 0; tap < ntap; ++tap) {
       const int buf = tap & 1;
@@ -681,15 +681,12 @@ int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* 
   p.act_on = act_alpha_dev != nullptr;
   p.act_alpha = act_alpha_dev;
   p.act_d = p.act_on ? (float)(1.0 / (double)(act_levels - 1)) : 1.0f;
-  {
-    const char* dbg = getenv("EFFQ_CONV_DEBUG");
-    p.debug = dbg ? atoi(dbg) : 0;
-  }
+  p.debug = effq_ablate_env("EFFQ_CONV_DEBUG");
   hipStream_t st = as_stream(stream);
   // (the ticket of the last-block reduction is left at zero by the kernel that used it: the caller zero-fills
   //  the workspace once, effq_hip.h)
   // loss-only calls of the short-K layers go to the direct-gather kernels
-  const int dkind = (out == nullptr && att == nullptr && !p.act_on && y_fp != nullptr && getenv("EFFQ_NO_DIRECT") == nullptr)
+  const int dkind = (out == nullptr && att == nullptr && !p.act_on && y_fp != nullptr && effq_ablate_env("EFFQ_NO_DIRECT") == 0)
                         ? conv_direct_kind(g) : 0;
   if (dkind != 0) {
     DirectParams dp;

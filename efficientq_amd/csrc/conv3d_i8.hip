@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
       hm |= (ok ? 1u : 0u) << k;
       R.h[k] = *reinterpret_cast<const v4i*>(p.x + (((nbase + cd) * p.H + chh) * p.W + cw) * 32 + part16);
     }
-    R.hmask = (p.debug == 2) ? 0u : hm;
+    R.hmask = (EFFQ_DBG(p) == 2) ? 0u : hm;
     // targets: register r holds voxel (row r>>2, column (r&3) + 4*lh) of d-plane wid, channel ch0 + li
     const int od = min(tl.od0 + wid, p.OD - 1);
     const bool dok = tl.od0 + wid < p.OD;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
       R.y[r] = p.y[rowoff[r >> 2] + coloff[r & 3]];
       ym |= (((rowok >> (r >> 2)) & (colok >> (r & 3)) & 1u) & (dok ? 1u : 0u)) << r;
     }
-    R.ymask = (p.debug == 3) ? 0u : ym;
+    R.ymask = (EFFQ_DBG(p) == 3) ? 0u : ym;
   };
 
   const int hv = (wid * I_HH + (li >> 3)) * I_HW + (li & 7);
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
     v16i acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0;
-    if (p.debug != 1)
+    if (EFFQ_DBG(p) != 1)
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
@@ -1250,10 +1250,7 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
   p.wstate = w_state_dev;
   p.inv_levels = 1.0 / ((double)(act_levels - 1) * (double)(w_levels - 1));
   p.sqerr = sqerr_out;
-  {
-    const char* dbg = getenv("EFFQ_I8_DEBUG");
-    p.debug = dbg ? atoi(dbg) : 0;
-  }
+  p.debug = effq_ablate_env("EFFQ_I8_DEBUG");
   hipStream_t st = as_stream(stream);
   // (the ticket of the last-block reduction is left at zero by the kernel that used it: the caller zero-fills
   //  the workspace once, effq_hip.h)
@@ -1272,7 +1269,7 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
       hipLaunchKernelGGL(k_conv3d_i8l2e, pl.grid, dim3(256), 0, st, p);
     else if (i8_two_plane(g))
       hipLaunchKernelGGL(k_conv3d_i8l2, pl.grid, dim3(256), 0, st, p);
-    else if (getenv("EFFQ_I8_REGS") != nullptr)      // register-resident variant kept for A/B comparison
+    else if (effq_ablate_env("EFFQ_I8_REGS") != 0)      // register-resident variant kept for A/B comparison
       hipLaunchKernelGGL(k_conv3d_i8<1>, pl.grid, dim3(256), 0, st, p);
     else
       hipLaunchKernelGGL(k_conv3d_i8l, pl.grid, dim3(256), 0, st, p);

@@ -238,9 +238,9 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
   __syncthreads();
   for (unsigned v0 = v_begin; v0 < v_end; v0 += KC, buf ^= 1) {
     const bool more = v0 + KC < v_end;
-    if (p.debug != 2) prefetch(more ? v0 + KC : v0);   // unconditional (the last chunk re-reads itself): lands
+    if (EFFQ_DBG(p) != 2) prefetch(more ? v0 + KC : v0);   // unconditional (the last chunk re-reads itself): lands
                                                         // in registers under the MFMAs below
-    if (rows_live && col_live[0] && p.debug != 1) {
+    if (rows_live && col_live[0] && EFFQ_DBG(p) != 1) {
       const float* pi = panI[buf];
       const float* pj = diag ? panI[buf] : panJ[buf];
       if (col_live[1]) {
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
           }
       }
     }
-    if (more && p.debug != 3) stage(buf ^ 1);
+    if (more && EFFQ_DBG(p) != 3) stage(buf ^ 1);
     __syncthreads();
   }
 #pragma unroll
@@ -407,10 +407,7 @@ int effq_gram_accum(const float* x_ndhwc, const float* att, const float* y_ndhwc
     set_error("gram: workspace %zu < required %zu", ws_bytes, need);
     return EFFQ_ERR_WORKSPACE;
   }
-  {
-    const char* dbg = getenv("EFFQ_GRAM_DEBUG");
-    p.debug = dbg ? atoi(dbg) : 0;
-  }
+  p.debug = effq_ablate_env("EFFQ_GRAM_DEBUG");
   p.x = x_ndhwc;
   p.att = att;
   p.y = y_ndhwc;

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
       const int ax = okx ? (e[0] * p.C1 + (off)) : 0;                                            \
       const int ay = e[2] * ystride + (off);                                                     \
       const int addr = (kind == 0) ? ax : ((kind == 1) ? ay : 0);                                \
-      val[q] = *reinterpret_cast<const gi_v4i*>(src + ((p.debug == 2) ? 0 : addr));             \
+      val[q] = *reinterpret_cast<const gi_v4i*>(src + ((EFFQ_DBG(p) == 2) ? 0 : addr));             \
       okb |= ok << q;                                                                            \
     }                                                                                            \
   }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
     GI_FETCH(vI, okI, kindI, tapI, offI, srcI, b ^ 1)          // chunk c+1 (its table was built last iteration)
     if (!diag) GI_FETCH(vJ, okJ, kindJ, tapJ, offJ, srcJ, b ^ 1)
     __builtin_amdgcn_sched_barrier(0);
-    if (live && p.debug != 1) {
+    if (live && EFFQ_DBG(p) != 1) {
       const unsigned char* PI = panI + b * GI_PANEL + (wr * 64 + li) * GI_RS + lh * 16;
       const unsigned char* PJ = (diag ? panI : panJ) + b * GI_PANEL + (wc * 64 + li) * GI_RS + lh * 16;
 #pragma unroll
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(GI_T, 2) void k_gram_i8(GramI8Params p) {
     }
     if (cls_next != cls_cur && live) flush(cls_cur);
     if (tid < GI_KC) tbl[b * GI_KC + tid] = traw;              // table of chunk c+2 replaces chunk c's
-    if (p.debug != 3) {
+    if (EFFQ_DBG(p) != 3) {
       stage(panI + (b ^ 1) * GI_PANEL, vI, okI, kindI);
       if (!diag) stage(panJ + (b ^ 1) * GI_PANEL, vJ, okJ, kindJ);
     }
@@ -473,10 +473,7 @@ int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const ef
   p.vox_list = vox_list;
   p.chunk_cls = chunk_cls;
   p.vtab = reinterpret_cast<const int*>(vtab);
-  {
-    const char* dbg = getenv("EFFQ_GI8_DEBUG");
-    p.debug = dbg ? atoi(dbg) : 0;
-  }
+  p.debug = effq_ablate_env("EFFQ_GI8_DEBUG");
   hipStream_t st = as_stream(stream);
   EFFQ_HIP(hipMemsetAsync(base, 0, 256 + slab_bytes, st));
   const size_t ny = (size_t)p.V * p.C2;
@@ -510,6 +507,170 @@ int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const ef
   hipLaunchKernelGGL(k_gram_i8_finish, dim3((unsigned)nb), dim3(256), 0, st, p, n, has_bias ? 1 : 0, act_alpha_dev,
                      act_levels, ymax, cls_w_dev, A0, B0, accumulate);
   EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+}  // extern "C"
+
+// ---- voxel list sorted by attention weight (the input format of effq_gram_accum_i8) ---------------------------------------
+// The reference's masks hold a handful of integer class weights (quirk Q1).  Three small launches replace a library
+// sort: (1) distinct values + counts through workgroup-local tables merged into a 32-slot global table, (2) one thread
+// orders the classes by value and lays out their 128-padded segments, (3) every workgroup reserves its share of each
+// segment with one atomic per class and writes its voxel indices.  The order of the voxels inside a class depends on
+// the scheduling - the Gram sums built on the list are exact integer sums, so they do not.
+namespace effq {
+constexpr int CLS_SLOTS = 32;      // table size; more than GI_MAX_CLS distinct values -> overflow (caller uses the fp32 Gram)
+constexpr int CLS_MAX = 16;
+struct ClsTable {
+  unsigned key[CLS_SLOTS];         // float bit pattern, 0xffffffff = empty
+  unsigned cnt[CLS_SLOTS];
+  unsigned cursor[CLS_MAX];        // next free entry of each class segment (scatter phase)
+  int overflow;
+  int ncls;
+  int n_list;                      // total length of the padded list
+  int slot_cls[CLS_SLOTS];         // table slot -> class index (by ascending value)
+  unsigned seg_start[CLS_MAX];
+  float cls_w[CLS_MAX];
+};
+
+__device__ __forceinline__ int cls_find_or_insert(unsigned* keys, unsigned k) {
+  unsigned h = (k * 2654435761u) >> 27;        // 5 bits
+  for (int probe = 0; probe < CLS_SLOTS; ++probe) {
+    const unsigned cur = atomicCAS(&keys[h], 0xffffffffu, k);
+    if (cur == 0xffffffffu || cur == k) return (int)h;
+    h = (h + 1) & (CLS_SLOTS - 1);
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(256) void k_cls_count(const float* __restrict__ att, long long V, ClsTable* t) {
+  __shared__ unsigned lkey[CLS_SLOTS], lcnt[CLS_SLOTS];
+  __shared__ int lover;
+  if (threadIdx.x < CLS_SLOTS) {
+    lkey[threadIdx.x] = 0xffffffffu;
+    lcnt[threadIdx.x] = 0u;
+  }
+  if (threadIdx.x == 0) lover = 0;
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += stride) {
+    const unsigned k = __float_as_uint(att[i]);
+    const int sidx = (k == 0xffffffffu) ? -1 : cls_find_or_insert(lkey, k);
+    if (sidx < 0)
+      lover = 1;
+    else
+      atomicAdd(&lcnt[sidx], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < CLS_SLOTS && lkey[threadIdx.x] != 0xffffffffu) {
+    const int g = cls_find_or_insert(t->key, lkey[threadIdx.x]);
+    if (g < 0)
+      t->overflow = 1;
+    else
+      atomicAdd(&t->cnt[g], lcnt[threadIdx.x]);
+  }
+  if (threadIdx.x == 0 && lover) t->overflow = 1;
+}
+
+__global__ void k_cls_layout(ClsTable* t, int* __restrict__ chunk_cls, int max_chunks) {
+  // one thread: order the (at most 32) used slots by value, give every class a segment padded to a multiple of 128
+  int used[CLS_SLOTS], nu = 0;
+  for (int sidx = 0; sidx < CLS_SLOTS; ++sidx)
+    if (t->key[sidx] != 0xffffffffu) used[nu++] = sidx;
+  if (nu > CLS_MAX) t->overflow = 1;
+  if (t->overflow) {
+    t->ncls = 0;
+    t->n_list = 0;
+    return;
+  }
+  for (int i = 1; i < nu; ++i) {               // insertion sort by float value
+    const int sidx = used[i];
+    const float v = __uint_as_float(t->key[sidx]);
+    int j = i - 1;
+    while (j >= 0 && __uint_as_float(t->key[used[j]]) > v) {
+      used[j + 1] = used[j];
+      --j;
+    }
+    used[j + 1] = sidx;
+  }
+  unsigned start = 0;
+  int chunk = 0;
+  for (int c = 0; c < nu; ++c) {
+    const int sidx = used[c];
+    t->slot_cls[sidx] = c;
+    t->cls_w[c] = __uint_as_float(t->key[sidx]);
+    t->seg_start[c] = start;
+    t->cursor[c] = start;
+    const unsigned padded = (t->cnt[sidx] + 127u) / 128u * 128u;
+    for (unsigned q = 0; q < padded / 128u && chunk < max_chunks; ++q) chunk_cls[chunk++] = c;
+    start += padded;
+  }
+  t->ncls = nu;
+  t->n_list = (int)start;
+}
+
+__global__ __launch_bounds__(256) void k_cls_scatter(const float* __restrict__ att, long long V, ClsTable* t,
+                                                     int* __restrict__ vox_list) {
+  __shared__ unsigned lcnt[CLS_MAX], lbase[CLS_MAX];
+  if (t->overflow) return;
+  if (threadIdx.x < CLS_MAX) lcnt[threadIdx.x] = 0u;
+  __syncthreads();
+  // contiguous slice per workgroup, two sweeps: count, reserve, write
+  const long long per = (V + gridDim.x - 1) / gridDim.x;
+  const long long i0 = (long long)blockIdx.x * per, i1 = (i0 + per < V) ? i0 + per : V;
+  for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const unsigned k = __float_as_uint(att[i]);
+    unsigned h = (k * 2654435761u) >> 27;
+    while (t->key[h] != k) h = (h + 1) & (CLS_SLOTS - 1);
+    atomicAdd(&lcnt[t->slot_cls[h]], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < CLS_MAX) {
+    lbase[threadIdx.x] = (lcnt[threadIdx.x] != 0u) ? atomicAdd(&t->cursor[threadIdx.x], lcnt[threadIdx.x]) : 0u;
+    lcnt[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const unsigned k = __float_as_uint(att[i]);
+    unsigned h = (k * 2654435761u) >> 27;
+    while (t->key[h] != k) h = (h + 1) & (CLS_SLOTS - 1);
+    const int c = t->slot_cls[h];
+    vox_list[lbase[c] + atomicAdd(&lcnt[c], 1u)] = (int)i;
+  }
+}
+}  // namespace effq
+
+extern "C" {
+
+size_t effq_att_classes_ws_bytes(void) { return sizeof(ClsTable) + 64; }
+
+/* Voxel list of an attention mask for effq_gram_accum_i8.  vox_list: V + 128*16 int32 (filled with -1 here, then the class
+ * segments), chunk_cls: (V / 128 + 16) int32, cls_w_dev: 16 floats.  info_host_out[3] = {ncls, n_list, overflow}: the call
+ * SYNCHRONISES the stream to return them (once per mask, not per layer: several layers share a pyramid level).
+ * overflow != 0: more than 16 distinct weights, the lists are not filled. */
+int effq_att_classes(const float* att, long long V, int32_t* vox_list, int32_t* chunk_cls, float* cls_w_dev,
+                     int32_t* info_host_out, void* ws, void* stream) {
+  EFFQ_CHECK_ARG(att && vox_list && chunk_cls && cls_w_dev && info_host_out && ws && V > 0 && V < (1ll << 31) - 4096);
+  hipStream_t st = as_stream(stream);
+  ClsTable* t = reinterpret_cast<ClsTable*>(ws);
+  EFFQ_HIP(hipMemsetAsync(t, 0, sizeof(ClsTable), st));
+  EFFQ_HIP(hipMemsetAsync(t->key, 0xff, sizeof(t->key), st));
+  const long long cap = V + 128 * CLS_MAX;
+  EFFQ_HIP(hipMemsetAsync(vox_list, 0xff, sizeof(int32_t) * (size_t)cap, st));     // -1 = padding
+  int blocks = (int)((V + 256 * 16 - 1) / (256 * 16));
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_cls_count, dim3(blocks), dim3(256), 0, st, att, V, t);
+  hipLaunchKernelGGL(k_cls_layout, dim3(1), dim3(1), 0, st, t, chunk_cls, (int)(V / 128 + CLS_MAX));
+  hipLaunchKernelGGL(k_cls_scatter, dim3(blocks), dim3(256), 0, st, att, V, t, vox_list);
+  EFFQ_LAUNCH_CHECK();
+  ClsTable host;
+  EFFQ_HIP(hipMemcpyAsync(&host, t, sizeof(ClsTable), hipMemcpyDeviceToHost, st));
+  EFFQ_HIP(hipStreamSynchronize(st));
+  info_host_out[0] = host.ncls;
+  info_host_out[1] = host.n_list;
+  info_host_out[2] = host.overflow;
+  if (!host.overflow) EFFQ_HIP(hipMemcpyAsync(cls_w_dev, t->cls_w, sizeof(float) * CLS_MAX, hipMemcpyDeviceToDevice, st));
   return EFFQ_OK;
 }
 

@@ -800,6 +800,38 @@ static int fixed_point_coop_impl(const float* a, const float* b, float* v_out, s
                                  (int)(FPC_SLICE * sizeof(float))));
     attr_set = true;
   }
+  // The grid barrier needs every workgroup resident at once.  That holds on a whole MI355X (G <= 256 = its CU count,
+  // one workgroup per CU by LDS); on a partitioned device (CPX / DPX), a smaller part, or with the CUs shared, it may
+  // not: then the fixed point runs as one launch per iteration (each a no-op once converged) - slower, never stuck.
+  static int resident_max[2] = {-1, -1};
+  if (resident_max[light] < 0) {
+    int dev = 0, ncu = 0, per_cu = 0;
+    EFFQ_HIP(hipGetDevice(&dev));
+    EFFQ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (light)
+      EFFQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fp_coop<512>, 512, FPC_SLICE / 2 * sizeof(float)));
+    else
+      EFFQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fp_coop<FPC_T>, FPC_T, FPC_SLICE * sizeof(float)));
+    resident_max[light] = ncu * per_cu;
+  }
+  if (G > resident_max[light]) {
+    RedWs r = red_ws(ws);
+    const float* src = a;
+    if (b != nullptr) {
+      hipLaunchKernelGGL(k_presum, dim3(stream_grid(n)), dim3(TPB), 0, st, a, b, v_out, n);
+      src = v_out;
+    }
+    double* s0 = r.partials + (size_t)RED_MAX_BLOCKS * (RED_SLOTS - 1);          // two spare doubles of the workspace
+    hipLaunchKernelGGL(k_reduce<0>, dim3(stream_grid((n + 3) / 4)), dim3(TPB), 0, st, src, n, (const double*)nullptr, 0.0,
+                       0.0, 0.0, (const int32_t*)nullptr, r.partials, r.ticket, s0);
+    hipLaunchKernelGGL(k_fp_init, dim3(1), dim3(1), 0, st, state_dev, s0);
+    const int grid = stream_grid((n + 3) / 4);
+    for (int i = 0; i < max_iter; ++i)
+      hipLaunchKernelGGL(k_fp_iter, dim3(grid), dim3(TPB), 0, st, src, n, state_dev, lo, hi, d, tol, max_iter, r.partials,
+                         r.ticket);
+    EFFQ_LAUNCH_CHECK();
+    return EFFQ_OK;
+  }
   if (light)
     hipLaunchKernelGGL(k_fp_coop<512>, dim3(G), dim3(512), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol, max_iter,
                        partials, counter);

@@ -287,8 +287,8 @@ class HipOps:
     def att_classes(self, att: Optional[torch.Tensor]):
         """Voxel list sorted by attention weight for effq_gram_accum_i8: (vox_list int32 padded per class to
         multiples of 128 with -1, chunk_cls int32, cls_w float32, ncls).  None when the mask has more distinct
-        values than the kernel takes (the caller then uses the fp32 Gram).  Plumbing only (a stable sort of
-        the voxel indices); cached per mask tensor, the pyramid level is shared by several layers."""
+        values than the kernel takes (the caller then uses the fp32 Gram).  Built by the library (effq_att_classes);
+        cached per mask tensor, the pyramid level is shared by several layers."""
         if att is None:
             return (None, None, None, 1)
         key = (att.data_ptr(), att.numel(), att._version)
@@ -296,22 +296,16 @@ class HipOps:
         if hit is not None:
             return hit[1]
         flat = self._f32(att).reshape(-1)
-        vals, inv = torch.unique(flat, return_inverse=True)
-        k = int(vals.numel())
-        if k > self.GRAM_I8_MAX_CLASSES:
-            res = None
-        else:
-            counts = torch.bincount(inv, minlength=k)
-            padded = (counts + 127) // 128 * 128
-            order = torch.argsort(inv, stable=True)
-            starts = torch.cumsum(counts, 0) - counts
-            pstarts = torch.cumsum(padded, 0) - padded
-            cls_sorted = inv[order]
-            dest = pstarts[cls_sorted] + (torch.arange(flat.numel(), device=flat.device) - starts[cls_sorted])
-            lst = torch.full((int(padded.sum().item()),), -1, dtype=torch.int32, device=flat.device)
-            lst[dest] = order.to(torch.int32)
-            chunk_cls = torch.repeat_interleave(torch.arange(k, dtype=torch.int32, device=flat.device), padded // 128)
-            res = (lst, chunk_cls.contiguous(), vals.to(torch.float32).contiguous(), k)
+        V = flat.numel()
+        lst = torch.empty(V + 128 * self.GRAM_I8_MAX_CLASSES, dtype=torch.int32, device=flat.device)
+        chunk_cls = torch.empty(V // 128 + self.GRAM_I8_MAX_CLASSES, dtype=torch.int32, device=flat.device)
+        cls_w = torch.empty(self.GRAM_I8_MAX_CLASSES, dtype=torch.float32, device=flat.device)
+        info = (C.c_int32 * 3)()
+        ws = self._workspace("att_cls", self.lib.effq_att_classes_ws_bytes())
+        check(self.lib.effq_att_classes(_ptr(flat), V, _ptr(lst), _ptr(chunk_cls), _ptr(cls_w), info, _ptr(ws),
+                                        self.stream), "effq_att_classes")
+        k, n_list, overflow = int(info[0]), int(info[1]), int(info[2])
+        res = None if overflow else (lst[:n_list], chunk_cls[: n_list // 128], cls_w[:k], k)
         if len(self._att_cache) > 16:
             self._att_cache.clear()
         self._att_cache[key] = (att, res)     # holding the mask keeps its address from being reused

@@ -369,7 +369,12 @@ class EfficientQConvHIP(PTQConv):
         if info["err"] != 0:                                               # layer_helper.py:62-64
             if info["err"] == 2:
                 raise RuntimeWarning(f'Exceed maximum iteration ({100 * self.qlvl_w}) for alpha optimization')
-            raise RuntimeError(f'weight-scale fixed point did not finish (device state {info["err"]})')
+            # state 3 = the grid barrier of the cooperative fixed point timed out (its workgroups were not co-resident):
+            # its barrier words in the reduction workspace are left non-zero - clear them before reporting
+            if hasattr(ops, "_red_ws"):
+                ops._red_ws.zero_()
+            raise RuntimeError(f'weight-scale fixed point did not finish (device state {info["err"]}: grid barrier '
+                               f'time-out of the cooperative kernel)')
         if hasattr(ops, "release_retired"):
             ops.release_retired()        # every stream was joined and the host has synchronised
         self.weight.data = best_G.reshape(self.weight.shape)               # (:147-158)

@@ -159,6 +159,16 @@ int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const ef
                        const int32_t* chunk_cls, const float* cls_w_dev, int ncls, long long n_list,
                        float* A0, float* B0, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* The voxel list of an attention mask, by three small kernels (distinct weights + counts, segment layout, scatter): the
+ * class weights are the few integers quirk Q1 leaves (ptqer.py:161-165).  vox_list: V + 2048 int32, chunk_cls: V/128 + 16
+ * int32, cls_w_dev: 16 floats, ws: effq_att_classes_ws_bytes().  info_host_out[3] = {ncls, n_list, overflow}; the call
+ * synchronises the stream to return them (once per mask; the layers of a pyramid level share it).  overflow != 0: more
+ * than 16 distinct weights (use effq_gram_accum).  The order of the voxels inside a class is not fixed; the sums of
+ * effq_gram_accum_i8 are exact integers, so its results do not depend on it. */
+size_t effq_att_classes_ws_bytes(void);
+int effq_att_classes(const float* att, long long V, int32_t* vox_list, int32_t* chunk_cls, float* cls_w_dev,
+                     int32_t* info_host_out, void* ws, void* stream);
+
 /* ---- a7: getAB + solve (solver.py:316-345) --------------------------------------
  * Ainv = (A0 + rho*I' + eta*I)^-1 in fp64 (I' has 0 on the bias diagonal), stored fp32 as n rows of
  * effq_ainv_ld(n) floats (row padding is zero; exactly symmetric).

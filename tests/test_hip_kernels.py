@@ -557,6 +557,35 @@ def test_cooperative_weight_fixed_point_matches_oracle(ops, n, L):
     assert ops.read_fp_state(st2) == (alpha, iters, done)
 
 
+def test_attention_class_lists_are_built_on_the_device(ops):
+    """effq_att_classes: the voxel list of a mask, grouped by attention weight (segments padded to multiples of 128 with
+    -1, classes in ascending order of weight) - checked as sets against torch; 17 distinct weights -> not representable."""
+    gen = torch.Generator().manual_seed(3)
+    for shape, vals in (((2, 9, 10, 11), [1.0, 2.0, 3.0]), ((1, 4, 4, 4), [2.0]), ((3, 16, 16, 16), [1.0, 5.0, 2.0, 7.0, 3.0])):
+        idx = torch.randint(0, len(vals), shape, generator=gen)
+        att = dev(torch.tensor(vals)[idx].float().contiguous())
+        ops._att_cache.clear()
+        lst, chunk_cls, cls_w, k = ops.att_classes(att)
+        want_vals = sorted(set(torch.unique(att).cpu().tolist()))
+        assert k == len(want_vals) and cls_w.cpu().tolist() == want_vals
+        lst_h, cc = lst.cpu(), chunk_cls.cpu()
+        assert lst_h.numel() % 128 == 0 and cc.numel() * 128 == lst_h.numel()
+        flat = att.reshape(-1).cpu()
+        pos = 0
+        for c, v in enumerate(want_vals):
+            members = torch.nonzero(flat == v).reshape(-1)
+            padded = (members.numel() + 127) // 128 * 128
+            seg = lst_h[pos: pos + padded]
+            assert torch.equal(torch.sort(seg[seg >= 0]).values, members.to(torch.int32))
+            assert (seg < 0).sum().item() == padded - members.numel()
+            assert torch.all(cc[pos // 128: (pos + padded) // 128] == c)
+            pos += padded
+        assert pos == lst_h.numel()
+    many = dev(torch.arange(17).float().repeat(100).reshape(1, 17, 10, 10).contiguous())
+    ops._att_cache.clear()
+    assert ops.att_classes(many) is None
+
+
 @pytest.mark.parametrize("n,c2", [(33, 3), (109, 32), (865, 32)])
 def test_gram_system_packs_into_one_message_and_back(ops, n, c2):
     """effq_gram_pack / effq_gram_unpack: upper triangle of A0 + B0, exact round trip; summing two packed partial systems

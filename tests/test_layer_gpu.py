@@ -375,7 +375,7 @@ def test_quantised_sliding_window_inference_and_dice_proxy(gold):
     """Row f1: the calibrated tiny net run patch-wise in quantized mode (every conv = conv3d_quant_calib_step with
     the activation quantiser fused), stitched like validate_seg, and scored against the FP network's predictions."""
     from efficientq_amd import calibrate as K, evaluate as E
-    g = gold("g6_tiny_lits_L4.npz")
+    g = gold("g6c_tiny_lits_L4.npz")     # (copy semantics: the product's default)
     args, model, _ = _tiny("lits")
     model.load_state_dict({k[4:]: T(g[k]) for k in g.files if k.startswith("sd0/")}, strict=False)
     model.eval()
