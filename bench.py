@@ -38,9 +38,9 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_model(levels, device):
+def build_model(levels, device, net="brats"):
     from efficientq_amd import calibrate as K, config as Cf, synth
-    args = Cf.make_args(Cf.BRATS_NET, levels, levels)
+    args = Cf.make_args(Cf.BRATS_NET if net == "brats" else Cf.LITS_NET, levels, levels)
     QConv, _, kwQ = Cf.get_conv_class(args)
     model = Cf.get_model_cube(args, QConv, kwQ)[0]["model"]
     synth.randomise_network(model, 0)          # same "pretrained" net on every rank
@@ -316,6 +316,8 @@ def main():
     ap.add_argument("--vols", type=int, default=16, help="calibration volumes per GPU")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--net", choices=["brats", "lits"], default="brats",
+                    help="brats = BASELINE configs[1] (the headline); lits = configs[3] geometry (1x160^3 volumes, widths to 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-subrun", action="store_true")
     ap.add_argument("--f32-only", action="store_true",
@@ -338,19 +340,22 @@ def main():
 
     from efficientq_amd import calibrate as K, synth
     from efficientq_amd.hip_ops import get_ops
-    args, model = build_model(a.levels, device)
+    args, model = build_model(a.levels, device, a.net)
+    if a.net == "lits" and a.size == 128:
+        a.size = 160
     pristine = {k: v.clone() for k, v in model.state_dict().items()}
     t = time.time()
     ids = range(rank * a.vols, (rank + 1) * a.vols)           # rank r holds its own shard of the volumes
-    vols = synth.calib_batch("brats", ids, a.size).to(device)
-    log(f"[rank {rank}] {a.vols} synthetic volumes 4x{a.size}^3 in HBM ({time.time() - t:.1f}s)")
+    vols = synth.calib_batch(a.net, ids, a.size).to(device)
+    nmod = 4 if a.net == "brats" else 1
+    log(f"[rank {rank}] {a.vols} synthetic volumes {nmod}x{a.size}^3 in HBM ({time.time() - t:.1f}s)")
 
     ops = get_ops(device)
     timer = OpTimer()
 
     def one_step():
         model.load_state_dict(pristine, strict=True)
-        return K.calibrate_model(model, vols, "brats", args.init_stride)
+        return K.calibrate_model(model, vols, a.net, args.init_stride)
 
     def fence():
         if world > 1:
@@ -382,6 +387,8 @@ def main():
     exact = bool(_Q.EXACT_INT_DEFAULT)
     if roof is not None:
         roof = dict(roof)
+    # 24.55 TFLOP per 4x128^3 BraTS volume, 99.69 per 1x160^3 LiTS volume (conv x 201 + Gram), scaled by voxels
+    tfv = (NET_TFLOP_PER_VOLUME * (a.size / 128.0) ** 3) if a.net == "brats" else (99.69 * (a.size / 160.0) ** 3)
     out = {
         "metric": "ptq_calibration_throughput", "value": round(total_vols / dt, 5), "unit": "calib-vols/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
@@ -389,18 +396,21 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "i8xi8->i32 (exact) for the Gram systems and per-iteration loss convs of the layers with quantised input, f32/f64 elsewhere"
                  if exact else "f32", "data": "synthetic",
-        "config": {"workload": f"BraTS 3D-UNet fp32->{a.levels}-level PTQ (qlvl_w={a.levels} qlvl_a={a.levels}, "
-                               f"q_first=q_last=256,-1), 22 quantised convs, 200 ADMM its/layer, "
-                               f"{a.vols} synthetic 4x{a.size}^3 volumes per GPU (BASELINE.json configs[1])",
-                   "vols_per_gpu": a.vols, "volume": f"4x{a.size}^3", "parallelism": f"dp{world}",
+        "config": {"workload": (f"BraTS 3D-UNet fp32->{a.levels}-level PTQ (qlvl_w={a.levels} qlvl_a={a.levels}, "
+                                f"q_first=q_last=256,-1), 22 quantised convs, 200 ADMM its/layer, "
+                                f"{a.vols} synthetic 4x{a.size}^3 volumes per GPU (BASELINE.json configs[1])")
+                   if a.net == "brats" else
+                   (f"LiTS 3D-UNet fp32->{a.levels}-level PTQ, 28 quantised convs (widths 32..512), 200 ADMM its/layer, "
+                    f"{a.vols} synthetic 1x{a.size}^3 volumes per GPU (BASELINE.json configs[3] geometry)"),
+                   "vols_per_gpu": a.vols, "volume": f"{nmod}x{a.size}^3", "parallelism": f"dp{world}",
                    "fp_pass_s": round(res["t1"] - res["t0"], 3), "ptq_pass_s": round(res["t2"] - res["t1"], 3)},
         "roofline": roof,
         "other_kernels": others,
         # (F_conv + F_gram) * N / wall over the f32 matrix peak, with the reference's fp32 ALGORITHMIC flops
         # (the exact-integer kernels do that work on the i8 matrix cores, so the fraction may exceed 1)
-        "achieved_mfma": {"algorithmic_tflop_per_volume": NET_TFLOP_PER_VOLUME,
-                          "tflops": round(NET_TFLOP_PER_VOLUME * total_vols / dt, 1), "peak": PEAK_F32_MFMA_TFLOPS,
-                          "frac_of_f32_peak": round(NET_TFLOP_PER_VOLUME * total_vols / dt / PEAK_F32_MFMA_TFLOPS, 3)},
+        "achieved_mfma": {"algorithmic_tflop_per_volume": tfv, "tflops": round(tfv * total_vols / dt, 1),
+                          "peak": PEAK_F32_MFMA_TFLOPS,
+                          "frac_of_f32_peak": round(tfv * total_vols / dt / PEAK_F32_MFMA_TFLOPS, 3)},
         # share of the wall clock the ops bracketed on each stream account for (loss and side overlap main)
         "stream_busy_frac": {k: round(v * 1e-3 / dt, 3) for k, v in busy.items()},
     }
@@ -420,7 +430,7 @@ def main():
         for m in model.modules():
             if hasattr(m, "lwq_exact_int"):
                 m.lwq_exact_int = True
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.net == "brats":
         log("[rank 0] timing the CPU baseline components ...")
         out["cpu_baseline"] = cpu_baseline(a.levels, a.vols, a.size)
     elif rank == 0:

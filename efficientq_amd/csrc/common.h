@@ -65,6 +65,17 @@ static inline RedWs red_ws(void* ws) {
 }
 
 #ifdef __HIPCC__
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence + barrier and the fence waits for
+// vmcnt(0): every global load in flight - i.e. the register prefetch of the NEXT tile - is drained at each barrier
+// (cdna_hip_programming.md, "Pipelining across barriers").  Tiles are handed over through LDS and registers only, so
+// the LDS counter is all the barrier needs: s_waitcnt lgkmcnt(0) (0xC07F: vmcnt and expcnt left alone) + s_barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // 64-lane wave sum of a double (all lanes end with lane 0's total valid).
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
 
   int tile = t_begin, slab = 0;
   for (int k = 0; k < nstage; ++k) {
-    __syncthreads();                             // LDS free
+    lds_barrier();                             // LDS free
 #pragma unroll
     for (int q = 0; q < G_MAXH; ++q) {
       const int u = tid + q * 256;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d(ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) ycur[nt][r] = ynext[nt][r];
     }
-    __syncthreads();
+    lds_barrier();
 
     int tile_n = tile, slab_n = slab + 1;
     if (slab_n == p.nslab) {
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
     float4 w0[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) w0[nt] = wsrc[nt * 32];
-    __syncthreads();                             // LDS (halo / ring / transpose buffer) is free
+    lds_barrier();                             // LDS (halo / ring / transpose buffer) is free
 #pragma unroll
     for (int q = 0; q < NHL; ++q) {
       const int u = tid + q * 256;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
 #pragma unroll
       for (int q = 0; q < NCELL; ++q) ycur[q] = ynext[q];
     }
-    __syncthreads();
+    lds_barrier();
 
     // prefetch of stage k+1 (next slab of this tile, or slab 0 + targets of the next tile)
     int tile_n = tile, slab_n = slab + 1;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) wbuf[(buf ^ 1) * (8 * 32 * NT) + wq * (32 * NT) + nt * 32 + wj] = wnext[nt];
       }
-      __syncthreads();
+      lds_barrier();
     }
 
     if (slab == p.nslab - 1) {
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_k3(ConvParams p) {
           acc[nt][r] = 0.0f;
         }
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int q = 0; q < NCELL; ++q) {
         const int u = tid + q * 256;

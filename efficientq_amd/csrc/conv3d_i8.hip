@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, (CG <= 4) ? 2 : 1) void k_conv3d_i8g(ConvI8Par
     load_y(t0, ynext);
   }
   for (int tile = t_begin; tile < t_end; ++tile) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
       const int u = tid + k * 256;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, (CG <= 4) ? 2 : 1) void k_conv3d_i8g(ConvI8Par
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) ycur[k] = ynext[k];
-    __syncthreads();
+    lds_barrier();
     if (tile + 1 < t_end) {
       const Tile tn = decode(tile + 1);
       load_halo(tn, hreg);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, (CG <= 4) ? 2 : 1) void k_conv3d_i8g(ConvI8Par
       const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
       tb[(wid * 32 + i) * I_TS + li] = (float)acc[r] * scale + bv;
     }
-    __syncthreads();
+    lds_barrier();
     const Tile tl = decode(tile);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Para
     load_y(t0, ynext, ymask_next);
   }
   for (int tile = t_begin; tile < t_end; ++tile) {
-    __syncthreads();                                       // halo free (previous tile's MFMAs done)
+    lds_barrier();                                       // halo free (previous tile's MFMAs done)
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
       const int u = tid + k * 256;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Para
 #pragma unroll
     for (int k = 0; k < 4; ++k) ycur[k] = ynext[k];
     ymask_cur = ymask_next;
-    __syncthreads();
+    lds_barrier();
     {
       const Tile tn = decode((tile + 1 < t_end) ? tile + 1 : tile);   // the last tile harmlessly re-reads itself
       load_halo(tn, hreg, hmask);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Para
       const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
       tb[(wid * 32 + i) * I_TS + li] = (float)acc[r] * scale + bv;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int u = tid + k * 256;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
   double l0 = 0.0;
   // one tile: store X's halo, refill X with tile+2, MFMAs, register epilogue against X's (saved) targets
   auto body = [&](int tile, Regs& X, bool more) {
-    __syncthreads();                                       // previous tile's MFMAs are done with the halo
+    lds_barrier();                                       // previous tile's MFMAs are done with the halo
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
       const int u = tid + k * 256;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) ycur[r] = X.y[r];
     const unsigned ymcur = X.ymask;
-    __syncthreads();
+    lds_barrier();
     fetch(more ? tile + 2 : tile, X);                      // two tiles ahead, into the set just consumed (the last
                                                            // two tiles harmlessly re-read themselves)
     __builtin_amdgcn_sched_barrier(0);
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2(ConvI8Params p) {
   const int hb0 = hv0 * VS + (wid * I_HH + (li >> 3)) * PADB, hb1 = hv1 * VS + ((wid + 4) * I_HH + (li >> 3)) * PADB;
   double l0 = 0.0;
   auto body = [&](int tile, Regs& X, bool more) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
       const int u = tid + k * 256;
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2(ConvI8Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) ycur[pl][r] = X.y[pl][r];
     const unsigned ym0 = X.ymask[0], ym1 = X.ymask[1];
-    __syncthreads();
+    lds_barrier();
     fetch(more ? tile + 2 : tile, X);
     __builtin_amdgcn_sched_barrier(0);
     v16i acc0, acc1;
@@ -741,6 +741,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
     const int j = u & 31, h = (u >> 5) & 1, tap = u >> 6;
     *reinterpret_cast<v4i*>(&wl[u * 16]) = *reinterpret_cast<const v4i*>(p.wq + ((size_t)(tap * p.c2p + j) * 32 + 16 * h));
   }
+  lds_barrier();
   const float scale = (float)((double)(*p.act_alpha) * (double)(float)p.wstate->alpha * p.inv_levels);
   const float bv = (p.bias != nullptr) ? p.bias[li] : 0.0f;
 
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
   const int hb1 = hb0 + 4 * I_HH * (I_HW * VS + PADB);
   double l0 = 0.0;
   auto body = [&](int tile, Regs& X, bool more) {
-    __syncthreads();
+    lds_barrier();
     if (X.hmask == 0xffffffffu) {
 #pragma unroll
       for (int k = 0; k < NHL; ++k)
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ycur[pl][r] = X.y[pl][r];
-    __syncthreads();
+    lds_barrier();
     fetch(more ? tile + 2 : tile, X);
     __builtin_amdgcn_sched_barrier(0);
     v16i acc0, acc1;
@@ -1007,7 +1008,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3d_i8p(ConvI8PairParams pp) {
 #pragma unroll
   for (int s = 0; s < NB; ++s) lsum[s] = 0.0;
   auto body = [&](int tile, Regs& X, bool more) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
       const int u = tid + k * 512;
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3d_i8p(ConvI8PairParams pp) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) ycur[pl][r] = X.y[pl][r];
     const unsigned ym0 = X.ymask[0], ym1 = X.ymask[1];
-    __syncthreads();
+    lds_barrier();
     fetch(more ? tile + 2 : tile, X);
     __builtin_amdgcn_sched_barrier(0);
     v16i acc[NB][2];
@@ -1118,6 +1119,9 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
                         : (g->C1 == 64 && i8_stream64()) ? wpc64 : 1;
   int gx = (256 * wg_per_cu + ny - 1) / ny;
   if (gx < 32) gx = 32;
+  // EFFQ_I8_TPW = tiles per workgroup: > 0 launches ntiles / TPW short-lived workgroups instead of a persistent grid
+  static const int tpw = getenv("EFFQ_I8_TPW") ? atoi(getenv("EFFQ_I8_TPW")) : 0;          // tuning aid
+  if (tpw > 0) gx = (p.ntiles + tpw - 1) / tpw;
   if (gx > p.ntiles) gx = p.ntiles;
   pl->grid = dim3((unsigned)gx, (unsigned)ny, 1);
   pl->nblk = (size_t)gx * ny;

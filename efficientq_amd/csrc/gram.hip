@@ -235,7 +235,7 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
     prefetch(v_begin);
     stage(0);
   }
-  __syncthreads();
+  lds_barrier();
   for (unsigned v0 = v_begin; v0 < v_end; v0 += KC, buf ^= 1) {
     const bool more = v0 + KC < v_end;
     if (EFFQ_DBG(p) != 2) prefetch(more ? v0 + KC : v0);   // unconditional (the last chunk re-reads itself): lands
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(GT) void k_gram(GramParams p) {
       }
     }
     if (more && EFFQ_DBG(p) != 3) stage(buf ^ 1);
-    __syncthreads();
+    lds_barrier();
   }
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt)

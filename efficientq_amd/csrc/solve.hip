@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_gj_diag(const double* __restrict__ A, i
       fcol[par][lane] = cp;
       if (lane == p) fcol[par][NBK] = 1.0 / cp;
     }
-    __syncthreads();
+    lds_barrier();
     const double piv = fcol[par][NBK];
     const double f = fcol[par][lane];
 #pragma unroll
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_gj_panel(double* __restrict__ A, int np
     }
   }
   load_tile(Bs, LDB_S, Dinv, NBK);
-  __syncthreads();
+  lds_barrier();
   // XT[kk][t*64 + r] = s * X[r][kk]   (coalesced along r)
   for (int e = tid; e < NBK * NBK; e += 256) {
     const int kk = e >> 6, r = e & 63;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_gj_trail_sym(double* __restrict__ A, in
     const int r = e >> 6, c = e & 63;
     As[r * LDA_S + c] = NZ[(size_t)(ib * NBK + r) * NBK + c];      // -Z_i
   }
-  __syncthreads();
+  lds_barrier();
   for (int t = 0; t < GJ_CT; ++t) {
     const int jb = blockIdx.x * GJ_CT + t;
     if (jb >= nblk || jb == kblk || jb < ib) continue;
@@ -272,6 +272,68 @@ __global__ __launch_bounds__(256) void k_build_b(const float* __restrict__ B0, c
   }
 }
 
+// The same, four columns per thread (row per blockIdx.y): for weight rows that are a multiple of 4 long (every layer of the
+// shipped nets but a 1-channel first conv) - 16-byte loads, no integer division per element.
+__global__ __launch_bounds__(256) void k_build_b4(const float* __restrict__ B0, const float* __restrict__ W0,
+                                                  const float* __restrict__ b0, const float* __restrict__ G,
+                                                  const float* __restrict__ dual, int c2, int n, int has_bias,
+                                                  float rho, float eta, float* __restrict__ Bm, int ldb,
+                                                  const float* __restrict__ wprev, float shift) {
+  const int r = blockIdx.y;
+  const int nw = n - has_bias;
+  float* out = Bm + (size_t)r * ldb;
+  for (int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k < ldb; k += gridDim.x * blockDim.x * 4) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < c2 && k < nw) {                       // nw % 4 == 0: a group of four never straddles the bias column
+      const size_t wi = (size_t)r * nw + k;
+      const float* bp = B0 + (size_t)r * n + k;   // (rows of B0 are n long: not 16-byte aligned in general)
+      const float4 w0 = *reinterpret_cast<const float4*>(W0 + wi), g = *reinterpret_cast<const float4*>(G + wi),
+                   du = *reinterpret_cast<const float4*>(dual + wi);
+      v.x = bp[0] + eta * w0.x;
+      v.y = bp[1] + eta * w0.y;
+      v.z = bp[2] + eta * w0.z;
+      v.w = bp[3] + eta * w0.w;
+      v.x = v.x + rho * (g.x - du.x);
+      v.y = v.y + rho * (g.y - du.y);
+      v.z = v.z + rho * (g.z - du.z);
+      v.w = v.w + rho * (g.w - du.w);
+      if (wprev != nullptr) {
+        const float4 wp = *reinterpret_cast<const float4*>(wprev + wi);
+        v.x = v.x + shift * wp.x;
+        v.y = v.y + shift * wp.y;
+        v.z = v.z + shift * wp.z;
+        v.w = v.w + shift * wp.w;
+      }
+    } else if (r < c2 && k == nw && has_bias) {
+      v.x = B0[(size_t)r * n + k] + eta * b0[r];
+    }
+    *reinterpret_cast<float4*>(out + k) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_prox_reduce4(const float* __restrict__ part, int ldp, int nsplit, int c2, int n,
+                                                      int has_bias, float* __restrict__ wstar, float* __restrict__ bstar) {
+  const int r = blockIdx.y;
+  const int nw = n - has_bias;
+  const size_t tot = (size_t)c2 * ldp;
+  const float* row = part + (size_t)r * ldp;
+  for (int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k < ldp; k += gridDim.x * blockDim.x * 4) {
+    if (k >= n) continue;
+    float4 v = *reinterpret_cast<const float4*>(row + k);
+    for (int z = 1; z < nsplit; ++z) {            // slice order: deterministic
+      const float4 t = *reinterpret_cast<const float4*>(row + (size_t)z * tot + k);
+      v.x += t.x;
+      v.y += t.y;
+      v.z += t.z;
+      v.w += t.w;
+    }
+    if (k < nw)
+      *reinterpret_cast<float4*>(wstar + (size_t)r * nw + k) = v;
+    else
+      bstar[r] = v.x;
+  }
+}
+
 // What = Bm * Ainv on the f32 matrix cores.  Ainv is exactly symmetric, so What[r][c] = sum_k Bm[r][k] *
 // Ainv[c][k]: BOTH operands are read along K (contiguous, 16-byte loads), staged as [row][32+4] tiles in
 // LDS (conflict-free ds_read_b128, 4 MFMAs per pair of reads) with the next K tile prefetched into
@@ -332,7 +394,7 @@ __global__ __launch_bounds__(256) void k_prox_gemm(const float* __restrict__ Bm,
   const int nk = (int)(((long long)nkt * (blockIdx.z + 1)) / gridDim.z);
   EFFQ_PROX_FETCH(kt0 * PBK)
   for (int kt = kt0; kt < nk; ++kt) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const int u = tid + q * 256;
@@ -343,7 +405,7 @@ __global__ __launch_bounds__(256) void k_prox_gemm(const float* __restrict__ Bm,
       const int u = tid + q * 256;
       *reinterpret_cast<f32x4*>(&Bs[(u >> 3) * PLD + (u & 7) * 4]) = rb[q];
     }
-    __syncthreads();
+    lds_barrier();
     EFFQ_PROX_FETCH(min(kt + 1, nk - 1) * PBK)   // unconditional: the last one is a harmless re-read
     __builtin_amdgcn_sched_barrier(0);           // keep the loads ahead of the MFMAs they hide under
 #pragma unroll
@@ -522,10 +584,17 @@ static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, 
   hipStream_t st = as_stream(stream);
   for (int term = 0; term < nterms; ++term) {
     {
-      size_t nb = ((size_t)c2p * ldb + 255) / 256;
-      if (nb > 4096) nb = 4096;
-      hipLaunchKernelGGL(k_build_b, dim3((unsigned)nb), dim3(256), 0, st, B0, W0, b0, G, dual, c2, n, has_bias ? 1 : 0,
-                         (float)rho, (float)eta, Bm, ldb, c2p, (term > 0) ? wstar : nullptr, (float)shift);
+      const int nw = n - (has_bias ? 1 : 0);
+      if ((nw % 4) == 0) {
+        const unsigned bx = (unsigned)((ldb / 4 + 255) / 256);
+        hipLaunchKernelGGL(k_build_b4, dim3(bx, (unsigned)c2p), dim3(256), 0, st, B0, W0, b0, G, dual, c2, n,
+                           has_bias ? 1 : 0, (float)rho, (float)eta, Bm, ldb, (term > 0) ? wstar : nullptr, (float)shift);
+      } else {
+        size_t nb = ((size_t)c2p * ldb + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(k_build_b, dim3((unsigned)nb), dim3(256), 0, st, B0, W0, b0, G, dual, c2, n, has_bias ? 1 : 0,
+                           (float)rho, (float)eta, Bm, ldb, c2p, (term > 0) ? wstar : nullptr, (float)shift);
+      }
       EFFQ_LAUNCH_CHECK();
     }
     const dim3 grid(pl.gx, pl.gy, pl.nsplit);
@@ -541,10 +610,17 @@ static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, 
 #undef EFFQ_PROX_LAUNCH
     EFFQ_LAUNCH_CHECK();
     if (pl.nsplit > 1) {
-      size_t nb = ((size_t)c2 * ldb + 255) / 256;
-      if (nb > 2048) nb = 2048;
-      hipLaunchKernelGGL(k_prox_reduce, dim3((unsigned)nb), dim3(256), 0, st, part, ldb, pl.nsplit, c2, n,
-                         has_bias ? 1 : 0, wstar, bstar);
+      const int nw = n - (has_bias ? 1 : 0);
+      if ((nw % 4) == 0) {
+        const unsigned bx = (unsigned)((ldb / 4 + 255) / 256);
+        hipLaunchKernelGGL(k_prox_reduce4, dim3(bx, (unsigned)c2), dim3(256), 0, st, part, ldb, pl.nsplit, c2, n,
+                           has_bias ? 1 : 0, wstar, bstar);
+      } else {
+        size_t nb = ((size_t)c2 * ldb + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(k_prox_reduce, dim3((unsigned)nb), dim3(256), 0, st, part, ldb, pl.nsplit, c2, n,
+                           has_bias ? 1 : 0, wstar, bstar);
+      }
       EFFQ_LAUNCH_CHECK();
     }
   }
