@@ -49,20 +49,24 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void k_gj_diag(const double* __restrict__ A, int npad, int kb,
-                                                 double* __restrict__ Dinv) {
+// 16 waves, 4 columns of the 64 x 64 block per wave (lane = row): a pivot step costs every wave 4 column updates
+// (the 4-wave version, 16 columns per wave, took 32 us per block - 64 serial steps of ~1500 cycles - on the critical
+// path of every inverse).
+constexpr int GJD_T = 1024, GJD_CPW = NBK / (GJD_T / 64);     // columns per wave = 4
+__global__ __launch_bounds__(GJD_T) void k_gj_diag(const double* __restrict__ A, int npad, int kb,
+                                                   double* __restrict__ Dinv) {
   __shared__ double fcol[2][NBK + 1];   // [parity][row] multipliers, [NBK] = 1/pivot
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  double reg[16];
+  double reg[GJD_CPW];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) reg[j] = A[(size_t)(kb + lane) * npad + kb + wid * 16 + j];
+  for (int j = 0; j < GJD_CPW; ++j) reg[j] = A[(size_t)(kb + lane) * npad + kb + wid * GJD_CPW + j];
 #pragma unroll
   for (int p = 0; p < NBK; ++p) {      // fully unrolled: pivot column / lane selectors become immediates
-    const int par = p & 1, wp = p >> 4, jp = p & 15;
+    const int par = p & 1, wp = p / GJD_CPW, jp = p % GJD_CPW;
     if (wid == wp) {
       double cp = reg[0];
 #pragma unroll
-      for (int j = 1; j < 16; ++j) cp = (jp == j) ? reg[j] : cp;
+      for (int j = 1; j < GJD_CPW; ++j) cp = (jp == j) ? reg[j] : cp;
       fcol[par][lane] = cp;
       if (lane == p) fcol[par][NBK] = 1.0 / cp;
     }
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void k_gj_diag(const double* __restrict__ A, i
     const double piv = fcol[par][NBK];
     const double f = fcol[par][lane];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < GJD_CPW; ++j) {
       const double rp = readlane_f64(reg[j], p) * piv;      // scaled pivot-row entry of this column
       const bool colp = (wid == wp) && (jp == j);
       double v;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void k_gj_diag(const double* __restrict__ A, i
     }
   }
 #pragma unroll
-  for (int j = 0; j < 16; ++j) Dinv[lane * NBK + wid * 16 + j] = reg[j];
+  for (int j = 0; j < GJD_CPW; ++j) Dinv[lane * NBK + wid * GJD_CPW + j] = reg[j];
 }
 
 // 64x64x64 fp64 tile product on the matrix cores: acc += As(64x64) * Bs(64x64), one 32x32 quadrant per wave.
@@ -544,7 +548,7 @@ int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double et
   }
   for (int k = 0; k < nblk; ++k) {
     const int kb = k * NBK;
-    hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(256), 0, st, A64, npad, kb, Dinv);
+    hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(GJD_T), 0, st, A64, npad, kb, Dinv);
     hipLaunchKernelGGL(k_gj_panel, dim3(nblk), dim3(256), lds, st, A64, npad, kb, Dinv, NZ, XT);
     if (nblk > 1)
       hipLaunchKernelGGL(k_gj_trail_sym, dim3((nblk + GJ_CT - 1) / GJ_CT, nblk), dim3(256), 0, st, A64, npad, kb, NZ, XT);
