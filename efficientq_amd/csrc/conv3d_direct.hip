@@ -5,8 +5,8 @@
 //     too short for channel-slab LDS tiling; here one wave owns 32 consecutive output voxels, its 54 B operands
 //     (27 taps x 2 K steps of v_mfma_f32_32x32x2_f32) sit in registers for the whole kernel and each lane gathers
 //     the two channels it feeds (8 bytes per tap) straight from L2 - no LDS, latency covered by occupancy.
-//   * k_conv1_small: 1x1x1 convs onto at most 4 output channels - the classifier (32 -> 3).  HBM-bound: LPV = C1/4
-//     lanes share a voxel (one coalesced 16-byte load each), partial dot products are reduced with DPP shuffles.
+//   * k_conv1_mfma: 1x1x1 convs onto at most 4 output channels - the classifier (32 -> 3).  HBM-bound streaming; the dot
+//     products run on v_mfma_f32_16x16x4_f32 (no cross-lane reduction).
 // Both end in the deterministic last-block reduction of common.h and write [sum d^2, sum d^2] like the tiled path.
 #include <stdint.h>
 #include <stdlib.h>
@@ -98,40 +98,56 @@ __global__ __launch_bounds__(256) void k_conv3d_c4(DirectParams p) {
   grid_sum_finish<2>(vsum, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
 }
 
-// 1x1x1 conv onto C2 <= 4 channels: LPV lanes per voxel, each owns 4 input channels
-template <int LPV>
-__global__ __launch_bounds__(256) void k_conv1_small(DirectParams p) {
+// 1x1x1 conv onto C2 <= 16 channels on the f32 matrix cores (v_mfma_f32_16x16x4_f32; the classifier uses 3 of the 16
+// columns - the matrix cores are idle anyway and the dot products need no cross-lane reduction this way).  One wave-tile
+// = 16 voxels: lane (row = l & 15, kq = l >> 4) loads the C1/4 consecutive channels [kq C1/4, (kq+1) C1/4) of voxel `row`
+// as float4s - the 64 lanes of a load instruction together cover whole cache lines of the 16 x C1 floats - and MFMA j
+// contracts channel kq C1/4 + j of every quarter (the B operand holds the weights in the same order).  U tiles are in
+// flight per wave (all loads of a body are issued before its first MFMA): HBM-bound streaming of 4 C1 + 4 C2 bytes/voxel.
+template <int C1, int U>
+__global__ __launch_bounds__(256) void k_conv1_mfma(DirectParams p) {
   __shared__ double red_smem[2 * 16];
   __shared__ int s_last;
-  const int tid = threadIdx.x;
-  const int sub = tid % LPV;            // channel quad of this lane
-  constexpr int VPB = 256 / LPV;        // voxels per block pass
-  float w[4][4];
+  constexpr int Q = C1 / 4, NV = Q / 4;          // floats / float4s per lane and tile
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int row = lane & 15, kq = lane >> 4;
+  float breg[Q];
 #pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[o][j] = (o < p.C2) ? p.G[(size_t)o * p.C1 + 4 * sub + j] : 0.0f;
-  float bv[4];
-#pragma unroll
-  for (int o = 0; o < 4; ++o) bv[o] = (p.bias != nullptr && o < p.C2) ? p.bias[o] : 0.0f;
-
+  for (int j = 0; j < Q; ++j) breg[j] = (row < p.C2) ? p.G[(size_t)row * C1 + kq * Q + j] : 0.0f;   // column = lane & 15
+  const float bv = (p.bias != nullptr && row < p.C2) ? p.bias[row] : 0.0f;
+  const long long ntile = (p.V + 15) / 16, nbody = (ntile + U - 1) / U;
+  const long long nwaves = (long long)gridDim.x * 4;
   double l0 = 0.0;
-  const long long stride = (long long)gridDim.x * VPB;
-  for (long long v = (long long)blockIdx.x * VPB + tid / LPV; v < p.V; v += stride) {
-    const d_f32x4 xv = *reinterpret_cast<const d_f32x4*>(p.x + v * p.C1 + 4 * sub);
-    float s[4];
+  for (long long body = (long long)blockIdx.x * 4 + wid; body < nbody; body += nwaves) {
+    d_f32x4 xv[U][NV];
+    float yv[U][4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) s[o] = ((xv[0] * w[o][0] + xv[1] * w[o][1]) + xv[2] * w[o][2]) + xv[3] * w[o][3];
+    for (int u = 0; u < U; ++u) {
+      const long long v0 = (body * U + u) * 16;
+      const long long vx = (v0 + row < p.V) ? v0 + row : p.V - 1;
 #pragma unroll
-    for (int m = 1; m < LPV; m <<= 1)
+      for (int q = 0; q < NV; ++q) xv[u][q] = *reinterpret_cast<const d_f32x4*>(p.x + vx * C1 + kq * Q + 4 * q);
 #pragma unroll
-      for (int o = 0; o < 4; ++o) s[o] += __shfl_xor(s[o], m);
-    if (sub == 0) {
-      for (int o = 0; o < p.C2; ++o) {
-        const float d = (s[o] + bv[o]) - p.y[v * p.C2 + o];
-        l0 += (double)d * (double)d;
+      for (int i = 0; i < 4; ++i) {
+        const long long vy = v0 + 4 * kq + i;        // output row 4 kq + i of the tile, column `row`
+        yv[u][i] = (vy < p.V && row < p.C2) ? p.y[vy * p.C2 + row] : 0.0f;
       }
     }
+    float s = 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      d_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int j = 0; j < Q; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][j >> 2][j & 3], breg[j], acc, 0, 0, 0);
+      const long long v0 = (body * U + u) * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = (v0 + 4 * kq + i < p.V) && row < p.C2;
+        const float d = (acc[i] + bv) - yv[u][i];
+        s = ok ? __builtin_fmaf(d, d, s) : s;
+      }
+    }
+    l0 += (double)s;
   }
   double vsum[2] = {l0, l0};
   grid_sum_finish<2>(vsum, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
@@ -158,15 +174,17 @@ int conv_direct_launch(int kind, DirectParams& p, size_t max_blocks, hipStream_t
     hipLaunchKernelGGL(k_conv3d_c4, dim3((unsigned)grid), dim3(256), 0, st, p);
     return EFFQ_OK;
   }
-  const int lpv = p.C1 / 4;
-  size_t grid = ((size_t)p.V * lpv + 255) / 256;
-  if (grid > 2048) grid = 2048;
+  static const size_t cap1 = getenv("EFFQ_C1_GRID") ? (size_t)atoi(getenv("EFFQ_C1_GRID")) : 1024;   // tuning aid
+  const size_t nbody4 = (size_t)((p.V + 63) / 64);
+  size_t grid = (nbody4 + 3) / 4;
+  if (grid > cap1) grid = cap1;
   if (grid > max_blocks) grid = max_blocks;
-  switch (lpv) {
-    case 8: hipLaunchKernelGGL(k_conv1_small<8>, dim3((unsigned)grid), dim3(256), 0, st, p); break;
-    case 16: hipLaunchKernelGGL(k_conv1_small<16>, dim3((unsigned)grid), dim3(256), 0, st, p); break;
-    case 32: hipLaunchKernelGGL(k_conv1_small<32>, dim3((unsigned)grid), dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL(k_conv1_small<64>, dim3((unsigned)grid), dim3(256), 0, st, p); break;
+  if (grid < 1) grid = 1;
+  switch (p.C1) {
+    case 32: hipLaunchKernelGGL((k_conv1_mfma<32, 4>), dim3((unsigned)grid), dim3(256), 0, st, p); break;
+    case 64: hipLaunchKernelGGL((k_conv1_mfma<64, 4>), dim3((unsigned)grid), dim3(256), 0, st, p); break;
+    case 128: hipLaunchKernelGGL((k_conv1_mfma<128, 2>), dim3((unsigned)grid), dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_conv1_mfma<256, 1>), dim3((unsigned)grid), dim3(256), 0, st, p); break;
   }
   return EFFQ_OK;
 }

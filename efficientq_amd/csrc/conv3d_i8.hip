@@ -1119,6 +1119,16 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
                         : (g->C1 == 64 && i8_stream64()) ? wpc64 : 1;
   int gx = (256 * wg_per_cu + ny - 1) / ny;
   if (gx < 32) gx = 32;
+  // The persistent grid leaves a few workgroup slots empty: the chain kernels of the NEXT iterate (prox GEMM, scale fixed
+  // point, projection) run beside this kernel and otherwise find no room until the persistent workgroups retire - chain
+  // and loss then serialise (32-channel layers: 0.104 ms per prox solve in situ against 0.053 with 16 slots free,
+  // 1222 -> 1190 ms per calibration).  The grid is trimmed to equal runs of tiles.  EFFQ_I8_RESERVE overrides (tuning aid).
+  static const int reserve = getenv("EFFQ_I8_RESERVE") ? atoi(getenv("EFFQ_I8_RESERVE")) : 16;
+  if (reserve > 0 && gx * ny > 2 * reserve) {
+    int g0 = gx - (reserve + ny - 1) / ny;
+    const int per = (p.ntiles + g0 - 1) / g0;
+    gx = (p.ntiles + per - 1) / per;
+  }
   // EFFQ_I8_TPW = tiles per workgroup: > 0 launches ntiles / TPW short-lived workgroups instead of a persistent grid
   static const int tpw = getenv("EFFQ_I8_TPW") ? atoi(getenv("EFFQ_I8_TPW")) : 0;          // tuning aid
   if (tpw > 0) gx = (p.ntiles + tpw - 1) / tpw;

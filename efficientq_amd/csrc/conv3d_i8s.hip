@@ -138,9 +138,18 @@ __global__ __launch_bounds__(256) void k_conv3d_i8s(ConvI8sParams p) {
   }
   const unsigned xorv = p.xor80 ? 0x80808080u : 0u;
 
-  double l0 = 0.0;
-  const int wave_global = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
-  for (int tile = wave_global; tile < p.ntiles; tile += nwaves) {
+  // Two tiles in flight per wave: the gathers and targets of tile i+1 are issued before the MFMA chain and the epilogue
+  // of tile i (a wave walks 4-8 tiles; with the loads inside the iteration every tile paid a full memory round trip).
+  constexpr bool PRE = CT <= 2;               // targets prefetched too (CT x 16 registers per buffer)
+  struct TileRegs {
+    s_v4i a[NJ];
+    float yv[PRE ? CT : 1][16];
+    unsigned okbits;                          // bit 4j + q: load (j, q) is a real tap
+    unsigned okmask[CT];                      // bit r: (row r of this lane, column 32 ct + li) is a real output
+    int su_lane;
+    long long v0;
+  };
+  auto fetch = [&](int tile, TileRegs& R) {
     const long long v = (long long)tile * 32 + li;
     const bool vvalid = v < p.V;
     int t = (int)(vvalid ? v : 0);
@@ -164,7 +173,42 @@ __global__ __launch_bounds__(256) void k_conv3d_i8s(ConvI8sParams p) {
       if (!vvalid) m = 0;
     }
     const int xbase = (((n * p.D + id0) * p.H + ih0) * p.W + iw0) * p.C1;
+    unsigned okb = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (C4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = (m >> tbit[j][q]) & 1u;
+          okb |= (ok ? 1u : 0u) << (4 * j + q);
+          R.a[j][q] = (int)*reinterpret_cast<const unsigned*>(p.x + (ok ? (xbase + toff[j][q]) : 0));
+        }
+      } else {
+        const bool ok = (m >> tbit[j][0]) & 1u;
+        okb |= (ok ? 1u : 0u) << (4 * j);
+        R.a[j] = *reinterpret_cast<const s_v4i*>(p.x + (ok ? (xbase + toff[j][0]) : 0));
+      }
+    }
+    R.okbits = okb;
+    R.v0 = (long long)tile * 32;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int col = 32 * ct + li;
+      unsigned mk = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long vr = R.v0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = vr < p.V && col < p.C2;
+        mk |= (ok ? 1u : 0u) << r;
+        if (PRE && p.su_out == nullptr) R.yv[PRE ? ct : 0][r] = p.y[ok ? vr * p.C2 + col : 0];
+      }
+      R.okmask[ct] = mk;
+    }
+    R.su_lane = (p.su_in != nullptr) ? p.su_in[vvalid ? v : 0] : 0;
+  };
 
+  double l0 = 0.0;
+  auto compute = [&](const TileRegs& R) {
     s_v16i acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -173,54 +217,55 @@ __global__ __launch_bounds__(256) void k_conv3d_i8s(ConvI8sParams p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       s_v4i a;
-      if (C4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool ok = (m >> tbit[j][q]) & 1u;
-          const int addr = ok ? (xbase + toff[j][q]) : 0;
-          const unsigned raw = *reinterpret_cast<const unsigned*>(p.x + addr);
-          a[q] = (int)((ok ? raw : 0u) ^ xorv);
-        }
-      } else {
-        const bool ok = (m >> tbit[j][0]) & 1u;
-        const int addr = ok ? (xbase + toff[j][0]) : 0;
-        const s_v4i raw = *reinterpret_cast<const s_v4i*>(p.x + addr);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = (int)((ok ? (unsigned)raw[q] : 0u) ^ xorv);
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = (R.okbits >> (4 * j + (C4 ? q : 0))) & 1u;
+        a[q] = (int)((ok ? (unsigned)R.a[j][q] : 0u) ^ xorv);
       }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, breg[j][ct], acc[ct], 0, 0, 0);
     }
-
     // epilogue: acc[ct][r] belongs to voxel row (r&3) + 8*(r>>2) + 4*lh of the tile, channel 32*ct + li
-    const long long v0 = (long long)tile * 32;
     if (p.su_out != nullptr) {       // sum mode: column 0 holds sum of the activation operands
       if (li == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const long long vr = v0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const long long vr = R.v0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (vr < p.V) p.su_out[vr] = acc[0][r] + p.aoff * p.K;
         }
       }
-      continue;
+      return;
     }
-    int su_lane = 0;
-    if (p.su_in != nullptr) su_lane = p.su_in[vvalid ? v : 0];
+    // squared errors: fp32 within the tile (4 chains), one fp64 addition per tile
+    float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const long long vr = v0 + row;
-      const int su = __shfl(su_lane, row);      // lane `row` (first half) holds voxel row's Su
+      const int su = (p.su_in != nullptr) ? __shfl(R.su_lane, row) : 0;    // lane `row` (first half) holds voxel row's Su
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const int col = 32 * ct + li;
-        if (vr < p.V && col < p.C2) {
-          const int num = p.wmul * (acc[ct][r] + p.aoff * ks[ct]) + su;
-          const float o = scale * (float)num + bv[ct];
-          const float d = o - p.y[vr * p.C2 + col];
-          l0 += (double)d * (double)d;
-        }
+        const bool ok = (R.okmask[ct] >> r) & 1u;
+        const float yy = PRE ? R.yv[PRE ? ct : 0][r] : p.y[ok ? (R.v0 + row) * p.C2 + 32 * ct + li : 0];
+        const int num = p.wmul * (acc[ct][r] + p.aoff * ks[ct]) + su;
+        const float dd = (scale * (float)num + bv[ct]) - yy;
+        s4[r & 3] = ok ? __builtin_fmaf(dd, dd, s4[r & 3]) : s4[r & 3];
       }
+    }
+    l0 += (double)((s4[0] + s4[1]) + (s4[2] + s4[3]));
+  };
+
+  const int wave_global = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
+  if (wave_global < p.ntiles) {
+    TileRegs A, B;
+    fetch(wave_global, A);
+    for (int tile = wave_global; tile < p.ntiles; tile += 2 * nwaves) {
+      const bool m1 = tile + nwaves < p.ntiles;
+      if (m1) fetch(tile + nwaves, B);
+      compute(A);
+      if (!m1) break;
+      const bool m2 = tile + 2 * nwaves < p.ntiles;
+      if (m2) fetch(tile + 2 * nwaves, A);
+      compute(B);
     }
   }
   if (p.su_out != nullptr) return;
@@ -267,8 +312,11 @@ static int i8s_plan(const effq_geom* g, int act_levels, int w_levels, I8sPlan* p
   p.inv_levels = 1.0 / ((double)(act_levels - 1) * (double)(w_levels - 1));
   // int32 range of the numerator
   EFFQ_CHECK_ARG((double)p.K * 255.0 * 255.0 * 2.0 < 2147483647.0);
+  // persistent: every workgroup pays a prologue (B operands, tap table) and one same-address ticket atomic (~12 ns
+  // each, serialised): a few workgroups per CU with several tiles per wave, not one tile per wave
+  static const int cap = getenv("EFFQ_I8S_GRID") ? atoi(getenv("EFFQ_I8S_GRID")) : 512;      // tuning aid
   int grid = (p.ntiles + 3) / 4;
-  if (grid > 4096) grid = 4096;
+  if (grid > cap) grid = cap;
   pl->grid = grid;
   pl->wq_bytes = (size_t)p.NJ * p.CT * 2 * 32 * 16;
   pl->su_bytes = (w_levels > 128) ? (size_t)p.V * sizeof(int) : 0;

@@ -25,7 +25,11 @@ for name, q in model.named_modules():
             tr = _o.__self__.last_trace
             print(f"  {_n:45s} {times[_n]:7.3f}s  loop {tr['admm_loop_s']:6.3f}s host-enqueue {tr['host_enqueue_s']:6.3f}s  in={tuple(x.shape)}", flush=True)
         q.ptq = timed
-res = K.calibrate_model(model, vols, "brats", args.init_stride)
+pristine = {k: v.clone() for k, v in model.state_dict().items()}
+for rep in range(int(os.environ.get("REPS", "1"))):
+    print(f"--- pass {rep}", flush=True)
+    model.load_state_dict(pristine)
+    res = K.calibrate_model(model, vols, "brats", args.init_stride)
 print(f"FP pass {res['t1']-res['t0']:.3f}s  PTQ pass {res['t2']-res['t1']:.3f}s  total {res['t2']-res['t0']:.3f}s  vols/s {N/(res['t2']-res['t0']):.4f}")
 print("\n".join(res["layer_loss"]))
 print("max mem GB", torch.cuda.max_memory_allocated() / 2**30)
