@@ -88,6 +88,51 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- DPP reductions over groups of GS lanes (GS a power of two <= 64); every lane of a 16-lane row ends with the
+// row's total, groups of 32 / 64 are finished with readlane.  Fixed tree: deterministic for fp64 too.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = dpp_u32<CTRL>((unsigned)u), hi = dpp_u32<CTRL>((unsigned)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+__device__ __forceinline__ unsigned group_sum_u32(unsigned v, int gs) {
+  if (gs >= 2) v += dpp_u32<DPP_XOR1>(v);
+  if (gs >= 4) v += dpp_u32<DPP_XOR2>(v);
+  if (gs >= 8) v += dpp_u32<DPP_HALF_MIRROR>(v);
+  if (gs >= 16) v += dpp_u32<DPP_MIRROR>(v);
+  if (gs >= 32) {
+    const int lane = threadIdx.x & 63;
+    const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16),
+                   r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    if (gs == 32)
+      v = (lane < 32) ? r0 + r1 : r2 + r3;
+    else
+      v = (r0 + r1) + (r2 + r3);
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
+  v += dpp_f64<DPP_XOR1>(v);
+  v += dpp_f64<DPP_XOR2>(v);
+  v += dpp_f64<DPP_HALF_MIRROR>(v);
+  v += dpp_f64<DPP_MIRROR>(v);
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  double r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, 16 * i), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 16 * i);
+    r[i] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
 // Block-wide sum of NS doubles per thread; result valid in thread 0.  smem: NS*16 doubles.
 template <int NS>
 __device__ __forceinline__ void block_sum(double (&v)[NS], double* smem) {

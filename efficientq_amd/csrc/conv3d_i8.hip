@@ -1121,9 +1121,9 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
   if (gx < 32) gx = 32;
   // The persistent grid leaves a few workgroup slots empty: the chain kernels of the NEXT iterate (prox GEMM, scale fixed
   // point, projection) run beside this kernel and otherwise find no room until the persistent workgroups retire - chain
-  // and loss then serialise (32-channel layers: 0.104 ms per prox solve in situ against 0.053 with 16 slots free,
+  // and loss then serialise (32-channel layers: 0.104 ms per prox solve in situ against 0.046 with 15 slots free (grid 497; 482 workgroups measured worse again),
   // 1222 -> 1190 ms per calibration).  The grid is trimmed to equal runs of tiles.  EFFQ_I8_RESERVE overrides (tuning aid).
-  static const int reserve = getenv("EFFQ_I8_RESERVE") ? atoi(getenv("EFFQ_I8_RESERVE")) : 16;
+  static const int reserve = getenv("EFFQ_I8_RESERVE") ? atoi(getenv("EFFQ_I8_RESERVE")) : 15;
   if (reserve > 0 && gx * ny > 2 * reserve) {
     int g0 = gx - (reserve + ny - 1) / ny;
     const int per = (p.ntiles + g0 - 1) / g0;

@@ -85,51 +85,6 @@ __device__ __forceinline__ long long fpb_units(float v, int b, const FpbGeo& g) 
   return __double2ll_rn(((double)v - ((double)(b - 1) * g.w - g.R64)) * g.rq);
 }
 
-// ---- DPP reductions over groups of GS lanes (GS a power of two <= 64); every lane of a 16-lane row ends with the
-// row's total, groups of 32 / 64 are finished with readlane.  Fixed tree: deterministic for fp64 too.
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = dpp_u32<CTRL>((unsigned)u), hi = dpp_u32<CTRL>((unsigned)(u >> 32));
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
-
-__device__ __forceinline__ unsigned group_sum_u32(unsigned v, int gs) {
-  if (gs >= 2) v += dpp_u32<DPP_XOR1>(v);
-  if (gs >= 4) v += dpp_u32<DPP_XOR2>(v);
-  if (gs >= 8) v += dpp_u32<DPP_HALF_MIRROR>(v);
-  if (gs >= 16) v += dpp_u32<DPP_MIRROR>(v);
-  if (gs >= 32) {
-    const int lane = threadIdx.x & 63;
-    const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16),
-                   r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
-    if (gs == 32)
-      v = (lane < 32) ? r0 + r1 : r2 + r3;
-    else
-      v = (r0 + r1) + (r2 + r3);
-  }
-  return v;
-}
-__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
-  v += dpp_f64<DPP_XOR1>(v);
-  v += dpp_f64<DPP_XOR2>(v);
-  v += dpp_f64<DPP_HALF_MIRROR>(v);
-  v += dpp_f64<DPP_MIRROR>(v);
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  double r[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, 16 * i), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 16 * i);
-    r[i] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-  }
-  return (r[0] + r[1]) + (r[2] + r[3]);
-}
-
 struct FpbShared {
   double thrS[2][257];       // per iteration parity: S(T_k) = sum of the values below boundary k
   unsigned thrC[2][257];     //                        C(T_k) = their count
@@ -330,6 +285,8 @@ template <int PER>   // register slots per thread (values stay in registers thro
 __global__ __launch_bounds__(FPS2_T) void k_fps(const float* __restrict__ a, const float* __restrict__ b2,
                                                 float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
                                                 double hi, double d, int levels, double tol, int max_iter) {
+  __builtin_amdgcn_s_setprio(3);        // latency-bound, shares its CU with loss-conv waves
+
   constexpr int B = FPS2_B;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // LDS: spre[B+1] f64 | off[B+2] u32 | vals[n] f32
@@ -578,6 +535,8 @@ static FpgWs fpg_carve(void* ws, size_t n) {
 
 __global__ __launch_bounds__(FPG_T) void k_fpg_sum(const float* __restrict__ a, const float* __restrict__ b2,
                                                    float* __restrict__ v_out, size_t n, FpgWs w) {
+  __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+
   __shared__ double s_red[16];
   __shared__ float s_mx[FPG_T / 64];
   __shared__ int s_last;
@@ -657,6 +616,8 @@ constexpr int FPG_B = 8192;                   // buckets of the multi-workgroup 
 constexpr int FPG_CT = 1024;                  // threads of the count kernel
 constexpr int FPG_SLICE = FPG_CT * FPG_EPT;   // values per workgroup
 __global__ __launch_bounds__(FPG_CT) void k_fpg_count(const float* __restrict__ src, size_t n, FpgWs w) {
+  __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* isum_l = reinterpret_cast<unsigned long long*>(smem_raw);     // [FPG_B]
   unsigned* cnt_l = reinterpret_cast<unsigned*>(isum_l + FPG_B);                     // [FPG_B]
@@ -707,6 +668,8 @@ __global__ __launch_bounds__(FPG_CT) void k_fpg_count(const float* __restrict__ 
 // scans the segment totals.
 constexpr int FPG_SEG = 1024;
 __global__ __launch_bounds__(FPG_SEG) void k_fpg_scan(int B, FpgWs w) {
+  __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+
   __shared__ unsigned s_wcnt[FPG_SEG / 64];
   __shared__ double s_wsum[FPG_SEG / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -768,6 +731,8 @@ __global__ __launch_bounds__(FPG_SEG) void k_fpg_scan(int B, FpgWs w) {
 __global__ __launch_bounds__(FPG_T) void k_fpg_scatter_iter(const float* __restrict__ src, size_t n, int B, FpgWs w,
                                                             effq_fp_state* st, double lo, double hi, double d, int levels,
                                                             double tol, int max_iter) {
+  __builtin_amdgcn_s_setprio(3);
+
   __shared__ FpbShared sh;
   __shared__ int s_last;
   const int tid = threadIdx.x;

@@ -232,12 +232,22 @@ constexpr int FPS_T = 1024;
 // runs ~300 iterations per ADMM iteration: the per-iteration latency (2.2 us with three barriers) is what counts.
 // PER = register slots per thread (compile time, so the element loop is branch-free and the fp64 chains of the
 // slots interleave).
+// Arithmetic per value: b = r d + lo is a function of the level index r alone, so
+//   sum b v = d sum(r v) + lo sum(v),   sum b^2 = d^2 sum(r^2) + 2 d lo sum(r) + lo^2 n
+// with sum(r), sum(r^2) exact integers and r v exact in fp64: per value ONE fp64 multiply-add instead of the ~16 fp64
+// operations of disc64_fast + two accumulations (fp64 min/max/rint/floor issue at a fraction of the fp32 rate; at 256
+// levels the first conv's weight scale takes ~290 iterations per ADMM iteration).  r comes from an fp32 evaluation of
+// u = (v/alpha - lo)/d (error <= 3e-5 at 256 levels) and is accepted when u is not within 2e-4 of a rounding boundary;
+// otherwise (2e-4 of the values) the reference's own fp64 arithmetic (disc64) decides: the level indices are exact.
 template <int T, int PER>
 __global__ __launch_bounds__(T) void k_fp_small(const float* __restrict__ a, const float* __restrict__ b2,
                                                 float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
                                                 double hi, double d, double tol, int max_iter) {
   constexpr int NW = T / 64;
-  __shared__ double part[2][2][NW];
+  __shared__ double part[2][3][NW];
+  // one workgroup on the critical path of the ADMM chain, sharing its CU with the waves of the loss conv of the previous
+  // iterate: ask the issue arbiter for priority
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int kmax = (int)((n + T - 1) / T);   // live register slots (uniform)
   float vr[PER];
@@ -254,46 +264,70 @@ __global__ __launch_bounds__(T) void k_fp_small(const float* __restrict__ a, con
     }
     vr[k] = v;
     acc0 += fabs((double)v);
+    acc1 += (double)v;
   }
-  acc0 = wave_sum(acc0);
-  if (lane == 0) part[0][0][wid] = acc0;
-  __syncthreads();
-  double tot = 0.0;
+  acc0 = wave_sum_f64_dpp(acc0);
+  acc1 = wave_sum_f64_dpp(acc1);
+  if (lane == 0) {
+    part[0][0][wid] = acc0;
+    part[0][1][wid] = acc1;
+  }
+  lds_barrier();
+  double tot = 0.0, sv = 0.0;                // sum |v|, sum v
 #pragma unroll
-  for (int w = 0; w < NW; ++w) tot += part[0][0][w];
+  for (int w = 0; w < NW; ++w) {
+    tot += part[0][0][w];
+    sv += part[0][1][w];
+  }
   double alpha = tot / (double)n, alpha_prev = -999.0;
-  double ralpha = (double)n / tot;           // disc64_fast only needs a reciprocal good to a few ulp
+  double ralpha = (double)n / tot;           // a reciprocal good to a few ulp is all the fast path needs
   double last0 = 0.0, last1 = 0.0;
   int it = 0, done = 0;
   const double rd = 1.0 / d;
+  const float c0 = (float)(-lo * rd), lmax = (float)rint((hi - lo) * rd);
+  const double lo_sv = lo * sv, lo2n = lo * lo * (double)n, d2 = d * d, dlo2 = 2.0 * d * lo;
   while (!done) {
-    const int par = (it + 1) & 1;            // parity 0 carried the abs-sum
-    acc0 = acc1 = 0.0;
+    const int par = (it + 1) & 1;            // parity 0 carried the prologue sums
+    const float c1 = (float)(ralpha * rd);
+    double arv = 0.0;
+    int sr = 0, sr2 = 0;                     // <= 32 slots x 255^2 per thread
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      // 1024 threads leave 128 VGPRs: interleaving the fp64 chains of all slots spills there, so that variant
-      // keeps a (uniform) branch per slot, which serialises them; the 256-thread variants run branch-free
+      // 1024 threads leave 128 VGPRs: interleaving the chains of all 32 slots spills there, so that variant keeps a
+      // (uniform) branch per slot; (a branch-free common path with the exact fallback hoisted out measured slower)
       if (T < 1024 || k < kmax) {
-        const double v = (double)vr[k];
-        double r;
-        const double bq = disc64_fast(v, alpha, ralpha, lo, hi, d, rd, &r);
-        acc0 += bq * v;                        // dead slots hold v = 0
-        acc1 += ((live >> k) & 1u) ? bq * bq : 0.0;
+        const float vf = vr[k];
+        float u = __builtin_fmaf(vf, c1, c0);
+        u = fminf(fmaxf(u, 0.0f), lmax);
+        float rf = rintf(u);
+        if (!(fabsf(u - rf) < 0.4998f)) {    // within 2e-4 of a rounding boundary (or NaN): exact arithmetic decides
+          double r;
+          disc64((double)vf, alpha, lo, hi, d, &r);
+          rf = (float)r;
+        }
+        const int ri = ((live >> k) & 1u) ? (int)rf : 0;      // dead slots hold v = 0: they must not count
+        sr += ri;
+        sr2 += ri * ri;
+        arv = __builtin_fma((double)rf, (double)vf, arv);     // r v is exact in fp64 (8 + 24 bits)
       }
     }
-    acc0 = wave_sum(acc0);
-    acc1 = wave_sum(acc1);
+    arv = wave_sum_f64_dpp(arv);
+    const unsigned wr = group_sum_u32((unsigned)sr, 64), wr2 = group_sum_u32((unsigned)sr2, 64);
     if (lane == 0) {
-      part[par][0][wid] = acc0;
-      part[par][1][wid] = acc1;
+      part[par][0][wid] = arv;
+      part[par][1][wid] = (double)wr;
+      part[par][2][wid] = (double)wr2;
     }
-    __syncthreads();
-    double t0 = 0.0, t1 = 0.0;
+    lds_barrier();
+    double trv = 0.0, tr = 0.0, tr2 = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      t0 += part[par][0][w];
-      t1 += part[par][1][w];
+      trv += part[par][0][w];
+      tr += part[par][1][w];
+      tr2 += part[par][2][w];
     }
+    const double t0 = d * trv + lo_sv;                         // sum b v
+    const double t1 = (d2 * tr2 + dlo2 * tr) + lo2n;           // sum b^2
     const double a_new = t0 / t1;
     const double ra_new = t1 / t0;           // independent of the division above (pipelines with it)
     ++it;
@@ -356,6 +390,8 @@ __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, cons
                                                    float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
                                                    double hi, double d, double tol, int max_iter, double* partials,
                                                    unsigned int* counter) {
+  __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+
   extern __shared__ __attribute__((aligned(16))) float vs[];      // this workgroup's slice of v
   __shared__ double smem[2 * 16];
   __shared__ double s_part[2 * FPC_MAXG];
@@ -503,6 +539,8 @@ __global__ __launch_bounds__(TPB) void k_project_dual(const float* __restrict__ 
                                                       float* __restrict__ G, float* __restrict__ dual,
                                                       float dual_div, int8_t* __restrict__ Gq, int lm1, size_t n,
                                                       int32_t* __restrict__ err_flag) {
+  __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+
   // (optional) the convergence check of the fixed point that produced `st`, folded in to save a launch
   if (err_flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && st->done != 1) *err_flag = (st->done == 2) ? 2 : 3;
   const double alpha = st->alpha;

@@ -283,6 +283,8 @@ __global__ __launch_bounds__(256) void k_build_b4(const float* __restrict__ B0, 
                                                   const float* __restrict__ dual, int c2, int n, int has_bias,
                                                   float rho, float eta, float* __restrict__ Bm, int ldb,
                                                   const float* __restrict__ wprev, float shift) {
+  __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+
   const int r = blockIdx.y;
   const int nw = n - has_bias;
   float* out = Bm + (size_t)r * ldb;
@@ -317,6 +319,8 @@ __global__ __launch_bounds__(256) void k_build_b4(const float* __restrict__ B0, 
 
 __global__ __launch_bounds__(256) void k_prox_reduce4(const float* __restrict__ part, int ldp, int nsplit, int c2, int n,
                                                       int has_bias, float* __restrict__ wstar, float* __restrict__ bstar) {
+  __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+
   const int r = blockIdx.y;
   const int nw = n - has_bias;
   const size_t tot = (size_t)c2 * ldp;
@@ -349,6 +353,8 @@ template <int MT, int WM, int WN, int NTN>
 __global__ __launch_bounds__(256) void k_prox_gemm(const float* __restrict__ Bm, int ldb, const float* __restrict__ Ainv,
                                                    int lda, int n, int c2, int has_bias, float* __restrict__ wstar,
                                                    float* __restrict__ bstar, float* __restrict__ part, int ldp) {
+  __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+
   constexpr int BM = 32 * MT * WM, BN = 32 * WN * NTN;
   constexpr int NA = BM * 8 / 256, NB = BN * 8 / 256;   // 16-byte loads per thread per K tile
   static_assert(WM * WN == 4 && NA >= 1 && NB >= 1, "4 waves");
@@ -484,21 +490,36 @@ __global__ __launch_bounds__(256) void k_prox_reduce(const float* __restrict__ p
 }
 
 // workgroup tile variant and K split of the prox GEMM: ~440 workgroups, >= 6 K tiles per slice (measured
-// best on MI355X for the BraTS sizes: scripts/prof_prox.py with EFFQ_PROX_SPLIT)
+// best on MI355X for the BraTS sizes: scripts/prof_prox.py with EFFQ_PROX_SPLIT).  The 256-row variant holds 3
+// workgroups per CU (104 VGPR + 64 AGPR, 45 KB LDS): ~760 workgroups fill the 768 slots evenly - with 545 some CUs
+// carried 3 and others 2 (c2 = 256, n = 6913: 325 -> 266 us per solve).
 struct ProxPlan { int variant, gx, gy, nsplit, c2p, ldb; };
 static ProxPlan prox_plan(int c2, int n) {
   ProxPlan p;
   p.c2p = (c2 > 128) ? round_up(c2, 256) : (c2 > 64) ? 128 : round_up(c2, 32);
   p.ldb = round_up(n, 32);
-  if (p.c2p >= 256) { p.variant = 0; p.gx = (n + 63) / 64; p.gy = p.c2p / 256; }        // 256x64, waves 64x64
+  static const int wide = getenv("EFFQ_PROX_WIDE") ? atoi(getenv("EFFQ_PROX_WIDE")) : 0;   // tuning aid
+  if (p.c2p >= 256 && wide) { p.variant = 4; p.gx = (n + 127) / 128; p.gy = p.c2p / 256; }   // 256x128, waves 64x128
+  else if (p.c2p >= 256) { p.variant = 0; p.gx = (n + 63) / 64; p.gy = p.c2p / 256; }        // 256x64, waves 64x64
   else if (p.c2p == 128) { p.variant = 1; p.gx = (n + 63) / 64; p.gy = 1; }             // 128x64, waves 32x64
   else if (p.c2p == 64) { p.variant = 2; p.gx = (n + 63) / 64; p.gy = 1; }              // 64x64, waves 32x32
   else { p.variant = 3; p.gx = (n + 127) / 128; p.gy = 1; }                             // 32x128, waves 32x32
   const int tiles = p.gx * p.gy, nkt = p.ldb / PBK;
-  int s = (440 + tiles - 1) / tiles;
+  static const int target_env = getenv("EFFQ_PROX_WGS") ? atoi(getenv("EFFQ_PROX_WGS")) : 0;   // tuning aid
+  int s = ((target_env > 0 ? target_env : 440) + tiles - 1) / tiles;
   if (s > nkt / 6) s = nkt / 6;
   if (s > 16) s = 16;
   if (s < 1) s = 1;
+  if (p.variant == 0 && target_env == 0) {
+    // fill the 768 slots (3 workgroups per CU) in whole rounds: the split with the best fill, smaller splits preferred
+    const int smax = s > 1 ? 16 : 1;
+    double best = -1.0;
+    for (int c = 1; c <= smax && c <= nkt / 6; ++c) {
+      const int wgs = tiles * c, rounds = (wgs + 767) / 768;
+      const double score = (double)wgs / (768.0 * rounds) - 0.01 * c;
+      if (score > best) { best = score; s = c; }
+    }
+  }
   static const int force = getenv("EFFQ_PROX_SPLIT") ? atoi(getenv("EFFQ_PROX_SPLIT")) : 0;   // tuning aid
   if (force > 0 && force <= nkt) s = force;
   p.nsplit = s;
@@ -607,6 +628,7 @@ static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, 
                      wstar, bstar, part, ldb)
     switch (pl.variant) {
       case 0: EFFQ_PROX_LAUNCH(2, 4, 1, 2); break;
+      case 4: EFFQ_PROX_LAUNCH(2, 4, 1, 4); break;
       case 1: EFFQ_PROX_LAUNCH(1, 4, 1, 2); break;
       case 2: EFFQ_PROX_LAUNCH(1, 2, 2, 1); break;
       default: EFFQ_PROX_LAUNCH(1, 1, 4, 1); break;
