@@ -393,83 +393,129 @@ __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, cons
   __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
 
   extern __shared__ __attribute__((aligned(16))) float vs[];      // this workgroup's slice of v
-  __shared__ double smem[2 * 16];
-  __shared__ double s_part[2 * FPC_MAXG];
-  __shared__ double s_tot[2];
+  constexpr int NW = T / 64;
+  __shared__ double s_wave[3][NW];
+  __shared__ double s_tot[3];
   __shared__ int s_fail;
-  const int tid = threadIdx.x, G = gridDim.x, wg = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, G = gridDim.x, wg = blockIdx.x;
   const size_t per = (n + G - 1) / G;
   const size_t s0 = (size_t)wg * per, s1 = (s0 + per < n) ? s0 + per : n;
   const int cnt = (s1 > s0) ? (int)(s1 - s0) : 0;
   if (tid == 0) s_fail = 0;
-  double acc[2] = {0.0, 0.0};
+  // workgroup sums of three doubles -> thread 0 (DPP wave sums, one LDS exchange; fixed tree: deterministic)
+  auto wg_sum3 = [&](double& x0, double& x1, double& x2) {
+    x0 = wave_sum_f64_dpp(x0);
+    x1 = wave_sum_f64_dpp(x1);
+    x2 = wave_sum_f64_dpp(x2);
+    if (lane == 0) {
+      s_wave[0][wid] = x0;
+      s_wave[1][wid] = x1;
+      s_wave[2][wid] = x2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        u0 += s_wave[0][w];
+        u1 += s_wave[1][w];
+        u2 += s_wave[2][w];
+      }
+      x0 = u0;
+      x1 = u1;
+      x2 = u2;
+    }
+  };
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   for (int i = tid; i < cnt; i += T) {
     const float v = (b2 != nullptr) ? (a[s0 + i] + b2[s0 + i]) : a[s0 + i];
     if (v_out != nullptr) v_out[s0 + i] = v;
     vs[i] = v;
-    acc[0] += fabs((double)v);
+    acc0 += fabs((double)v);
+    acc1 += (double)v;
   }
-  block_sum<2>(acc, smem);
+  wg_sum3(acc0, acc1, acc2);
   unsigned epoch = 0;
-  // partials layout: [parity][wg][2]
+  // partials layout: [parity][wg][3]
   if (tid == 0) {
-    partials[(0 * FPC_MAXG + wg) * 2 + 0] = acc[0];
-    partials[(0 * FPC_MAXG + wg) * 2 + 1] = 0.0;
+    partials[(0 * FPC_MAXG + wg) * 3 + 0] = acc0;
+    partials[(0 * FPC_MAXG + wg) * 3 + 1] = acc1;
+    partials[(0 * FPC_MAXG + wg) * 3 + 2] = 0.0;
   }
   if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail)) {
     if (wg == 0 && tid == 0) st->done = 3;
     return;
   }
-  // the G partials are fetched by G lanes (one agent-scope load each), added by ONE thread in workgroup order
-  // (identical value in every workgroup, run to run) and broadcast through LDS -- every thread re-reading
-  // all G partials costs 2*G*1024 uncached loads per workgroup per iteration and dominated the iteration
-  auto combine = [&](int par, double& t0, double& t1) {
-    if (tid < G) {
-      s_part[tid] = __hip_atomic_load(&partials[(par * FPC_MAXG + tid) * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_part[FPC_MAXG + tid] = __hip_atomic_load(&partials[(par * FPC_MAXG + tid) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double u0 = 0.0, u1 = 0.0;
-      for (int g = 0; g < G; ++g) {
-        u0 += s_part[g];
-        u1 += s_part[FPC_MAXG + g];
+  // the G partials are fetched by the lanes of wave 0 (agent-scope loads, lane l takes workgroups l, l + 64, ...) and
+  // added by a fixed DPP tree: the same bits in every workgroup and run to run; the totals go to all threads through LDS
+  auto combine = [&](int par, double& t0, double& t1, double& t2) {
+    if (wid == 0) {
+      double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+      for (int g = lane; g < G; g += 64) {
+        u0 += __hip_atomic_load(&partials[(par * FPC_MAXG + g) * 3 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u1 += __hip_atomic_load(&partials[(par * FPC_MAXG + g) * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u2 += __hip_atomic_load(&partials[(par * FPC_MAXG + g) * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      s_tot[0] = u0;
-      s_tot[1] = u1;
+      u0 = wave_sum_f64_dpp(u0);
+      u1 = wave_sum_f64_dpp(u1);
+      u2 = wave_sum_f64_dpp(u2);
+      if (lane == 0) {
+        s_tot[0] = u0;
+        s_tot[1] = u1;
+        s_tot[2] = u2;
+      }
     }
     __syncthreads();
     t0 = s_tot[0];
     t1 = s_tot[1];
+    t2 = s_tot[2];
     __syncthreads();
   };
-  double tot = 0.0, tdummy = 0.0;
-  combine(0, tot, tdummy);
+  double tot = 0.0, sv = 0.0, tdummy = 0.0;
+  combine(0, tot, sv, tdummy);
   double alpha = tot / (double)n, alpha_prev = -999.0;
   int it = 0, done = 0;
   double last0 = 0.0, last1 = 0.0;
+  // per value: level index r from an fp32 evaluation (exact fp64 arithmetic within 2e-4 of a rounding boundary), then
+  // sum b v = d sum(r v) + lo sum(v), sum b^2 = d^2 sum(r^2) + 2 d lo sum(r) + lo^2 n (see k_fp_small)
+  const double rd = 1.0 / d;
+  const float c0 = (float)(-lo * rd), lmax = (float)rint((hi - lo) * rd);
+  const double lo_sv = lo * sv, lo2n = lo * lo * (double)n, d2 = d * d, dlo2 = 2.0 * d * lo;
   while (!done) {
     const int par = (it + 1) & 1;          // parity 0 was used by the abs-sum epoch
-    acc[0] = acc[1] = 0.0;
-    const double ralpha = 1.0 / alpha, rd = 1.0 / d;
+    const float c1 = (float)((1.0 / alpha) * rd);
+    double arv = 0.0;
+    long long sr = 0, sr2 = 0;
     for (int i = tid; i < cnt; i += T) {
-      const double v = (double)vs[i];
-      double r;
-      const double bq = disc64_fast(v, alpha, ralpha, lo, hi, d, rd, &r);
-      acc[0] += bq * v;
-      acc[1] += bq * bq;
+      const float vf = vs[i];
+      float u = __builtin_fmaf(vf, c1, c0);
+      u = fminf(fmaxf(u, 0.0f), lmax);
+      float rf = rintf(u);
+      if (!(fabsf(u - rf) < 0.4998f)) {
+        double r;
+        disc64((double)vf, alpha, lo, hi, d, &r);
+        rf = (float)r;
+      }
+      const int ri = (int)rf;
+      sr += ri;
+      sr2 += ri * ri;
+      arv = __builtin_fma((double)rf, (double)vf, arv);
     }
-    block_sum<2>(acc, smem);
+    double dr = (double)sr, dr2 = (double)sr2;
+    wg_sum3(arv, dr, dr2);
     if (tid == 0) {
-      partials[(par * FPC_MAXG + wg) * 2 + 0] = acc[0];
-      partials[(par * FPC_MAXG + wg) * 2 + 1] = acc[1];
+      partials[(par * FPC_MAXG + wg) * 3 + 0] = arv;
+      partials[(par * FPC_MAXG + wg) * 3 + 1] = dr;
+      partials[(par * FPC_MAXG + wg) * 3 + 2] = dr2;
     }
     if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail)) {
       if (wg == 0 && tid == 0) st->done = 3;
       return;
     }
-    double t0 = 0.0, t1 = 0.0;
-    combine(par, t0, t1);
+    double trv = 0.0, tr = 0.0, tr2 = 0.0;
+    combine(par, trv, tr, tr2);
+    const double t0 = d * trv + lo_sv;                         // sum b v
+    const double t1 = (d2 * tr2 + dlo2 * tr) + lo2n;           // sum b^2
     const double a_new = t0 / t1;
     alpha_prev = alpha;
     ++it;
@@ -822,7 +868,7 @@ static int fixed_point_coop_impl(const float* a, const float* b, float* v_out, s
   EFFQ_CHECK_ARG(G <= FPC_MAXG);
   const size_t per = (n + G - 1) / G;
   const size_t lds = per * sizeof(float);
-  // workspace: reuse the reduction workspace: partials [2][FPC_MAXG][2] doubles at its start
+  // workspace: reuse the reduction workspace: partials [2][FPC_MAXG][3] doubles at its start
   double* partials = reinterpret_cast<double*>(ws);
   // the two counter words sit in the tail of the reduction workspace (after the ticket), where no reduction kernel
   // writes partial sums: they must still be zero from the previous launch
