@@ -98,6 +98,163 @@ __global__ __launch_bounds__(256) void k_conv3d_c4(DirectParams p) {
   grid_sum_finish<2>(vsum, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
 }
 
+// ---- the same conv with the input staged through LDS -------------------------------------------------------------
+// k_conv3d_c4 gathers every tap straight from L1/L2: 27 gathers of 8 bytes per lane and tile, 16 cache lines each at
+// stride 2 - the texture path, not HBM or the matrix cores, set its 0.52 ms (26 % of 8 TB/s).  Here a workgroup owns
+// 4 x 4 x 8 output voxels (wave w = d-plane w), stages their ((4-1)S+3) x ((4-1)S+3) x ((8-1)S+3) input voxels (16 bytes
+// each) once through LDS - coalesced 16-byte loads, prefetched into registers under the MFMAs of the previous tile - and
+// every tap is one ds_read_b64 per lane.  Measured (16 x 4 x 128^3, stride 2): 0.44 ms against 0.52; with the MFMA chain
+// removed 0.25 ms (1.26 GB incl. halo overlap = 5.1 TB/s), with the loads removed 0.28 ms (K = 108 on
+// v_mfma_f32_32x32x2_f32 is 54 instructions of 64 cycles per 32 x 32 outputs: 0.18 ms at full issue rate), with both
+// removed 0.07 ms: the two phases still add up instead of overlapping at 2 workgroups per CU (254 VGPRs).
+// S = stride (1 or 2, isotropic); persistent workgroups walk contiguous runs of tiles.
+constexpr int C4_TD = 4, C4_TH = 4, C4_TW = 8;
+template <int S>
+__global__ __launch_bounds__(256, 2) void k_conv3d_c4h(DirectParams p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
+  constexpr int HD = (C4_TD - 1) * S + 3, HH = (C4_TH - 1) * S + 3, HW = (C4_TW - 1) * S + 3, NHV = HD * HH * HW;
+  constexpr int NHL = (NHV + 255) / 256;
+  constexpr int T = 27;
+  __shared__ __attribute__((aligned(16))) float halo[NHV * 4];
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+
+  float breg[T][2];
+#pragma unroll
+  for (int tap = 0; tap < T; ++tap)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) breg[tap][e] = p.G[((size_t)li * 4 + 2 * lh + e) * T + tap];   // G [C2][C1][T]
+  const float bv = (p.bias != nullptr) ? p.bias[li] : 0.0f;
+
+  // per-thread halo voxels (relative coordinates and offsets fixed at start)
+  int hcd[NHL], hch[NHL], hcw[NHL];
+  long long hrel[NHL];
+#pragma unroll
+  for (int k = 0; k < NHL; ++k) {
+    const int u = tid + k * 256;
+    const int v = (u < NHV) ? u : 0;
+    hcw[k] = v % HW;
+    const int t2 = v / HW;
+    hch[k] = t2 % HH;
+    const int hd = t2 / HH;
+    hcd[k] = (u < NHV) ? hd : (1 << 20);            // dead slot: never in range
+    hrel[k] = (((long long)hd * p.H + hch[k]) * p.W + hcw[k]) * 4;
+  }
+  int yrel[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;                // voxel of the plane: h = i >> 3, w = i & 7
+    yrel[r] = ((i >> 3) * p.OW + (i & 7)) * 32 + li;
+  }
+  // A fragment of this lane: output voxel (plane wid, h = li >> 3, w = li & 7), channels 2 lh, 2 lh + 1
+  const int abase = (((wid * S) * HH + (li >> 3) * S) * HW + (li & 7) * S) * 4 + 2 * lh;
+
+  const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per;
+  const int t_end = (t_begin + per < ntiles) ? t_begin + per : ntiles;
+
+  d_f32x4 hreg[NHL];
+  float ynext[16], ycur[16];
+  unsigned hmask = 0, ymask_next = 0, ymask_cur = 0;
+  auto fetch = [&](int tile) {
+    int t = tile;
+    const int ow0 = (t % tiles_w) * C4_TW;
+    t /= tiles_w;
+    const int oh0 = (t % tiles_h) * C4_TH;
+    t /= tiles_h;
+    const int od0 = (t % tiles_d) * C4_TD;
+    const int n = t / tiles_d;
+    const int id0 = od0 * S - p.PD, ih0 = oh0 * S - p.PH, iw0 = ow0 * S - p.PW;
+    // tiles that touch no face of the input or output volume (uniform test): one base address + per-lane offsets
+    const bool interior = id0 >= 0 && id0 + HD <= p.D && ih0 >= 0 && ih0 + HH <= p.H && iw0 >= 0 && iw0 + HW <= p.W &&
+                          od0 + C4_TD <= p.OD && oh0 + C4_TH <= p.OH && ow0 + C4_TW <= p.OW;
+    if (interior) {
+      const float* hb = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * 4;
+#pragma unroll
+      for (int k = 0; k < NHL; ++k) hreg[k] = *reinterpret_cast<const d_f32x4*>(hb + ((hcd[k] < HD) ? hrel[k] : 0));
+      hmask = 0xffffffffu;
+      const float* yb = p.y + ((((long long)n * p.OD + od0 + wid) * p.OH + oh0) * p.OW + ow0) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ynext[r] = yb[yrel[r]];
+      ymask_next = 0xffffu;
+      return;
+    }
+    unsigned hm = 0;
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int id = id0 + hcd[k], ih = ih0 + hch[k], iw = iw0 + hcw[k];
+      const bool ok = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+      const int cd = min(max(id, 0), p.D - 1), chh = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
+      hm |= (ok ? 1u : 0u) << k;
+      hreg[k] = *reinterpret_cast<const d_f32x4*>(p.x + ((((size_t)n * p.D + cd) * p.H + chh) * p.W + cw) * 4);
+    }
+    hmask = hm;
+    const int od = od0 + wid;
+    unsigned ym = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int oh = oh0 + (i >> 3), ow = ow0 + (i & 7);
+      const bool ok = od < p.OD && oh < p.OH && ow < p.OW;
+      ym |= (ok ? 1u : 0u) << r;
+      ynext[r] = p.y[((((size_t)n * p.OD + min(od, p.OD - 1)) * p.OH + min(oh, p.OH - 1)) * p.OW + min(ow, p.OW - 1)) * 32 + li];
+    }
+    ymask_next = ym;
+  };
+
+  double l0 = 0.0;
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    lds_barrier();                                         // the previous tile's fragment reads are done
+    if (hmask == 0xffffffffu) {
+#pragma unroll
+      for (int k = 0; k < NHL; ++k)
+        if (tid + k * 256 < NHV) *reinterpret_cast<d_f32x4*>(&halo[(tid + k * 256) * 4]) = hreg[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NHL; ++k) {
+        const int u = tid + k * 256;
+        const d_f32x4 val = ((hmask >> k) & 1u) ? hreg[k] : d_f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // zero padding
+        if (u < NHV) *reinterpret_cast<d_f32x4*>(&halo[u * 4]) = val;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ycur[r] = ynext[r];
+    ymask_cur = ymask_next;
+    lds_barrier();
+    fetch((tile + 1 < t_end) ? tile + 1 : tile);           // the last tile harmlessly re-reads itself
+    __builtin_amdgcn_sched_barrier(0);
+    d_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const d_f32x2 a = *reinterpret_cast<const d_f32x2*>(&halo[abase + ((kd * HH + kh) * HW + kw) * 4]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], breg[tap][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], breg[tap][1], acc, 0, 0, 0);
+    }
+    float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ymask_cur == 0xffffu) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = (acc[r] + bv) - ycur[r];
+        s4[r & 3] = __builtin_fmaf(d, d, s4[r & 3]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = (acc[r] + bv) - ycur[r];
+        s4[r & 3] = ((ymask_cur >> r) & 1u) ? __builtin_fmaf(d, d, s4[r & 3]) : s4[r & 3];
+      }
+    }
+    l0 += (double)((s4[0] + s4[1]) + (s4[2] + s4[3]));
+  }
+  double vsum[2] = {l0, l0};
+  grid_sum_finish<2>(vsum, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
+}
+
 // 1x1x1 conv onto C2 <= 16 channels on the f32 matrix cores (v_mfma_f32_16x16x4_f32; the classifier uses 3 of the 16
 // columns - the matrix cores are idle anyway and the dot products need no cross-lane reduction this way).  One wave-tile
 // = 16 voxels: lane (row = l & 15, kq = l >> 4) loads the C1/4 consecutive channels [kq C1/4, (kq+1) C1/4) of voxel `row`
@@ -164,6 +321,23 @@ int conv_direct_kind(const effq_geom* g) {
 int conv_direct_launch(int kind, DirectParams& p, size_t max_blocks, hipStream_t st) {
   if ((long long)p.N * p.D * p.H * p.W * p.C1 >= (1ll << 31) || p.V >= (1ll << 31)) return EFFQ_ERR_ARG;
   p.ntiles = (int)((p.V + 31) / 32);
+  if (kind == 1 && p.SD == p.SH && p.SH == p.SW && (p.SD == 1 || p.SD == 2)) {
+    static const int use_lds = getenv("EFFQ_C4_LDS") ? atoi(getenv("EFFQ_C4_LDS")) : 1;      // tuning aid
+    if (use_lds) {
+      const int td = (p.OD + C4_TD - 1) / C4_TD, th = (p.OH + C4_TH - 1) / C4_TH, tw = (p.OW + C4_TW - 1) / C4_TW;
+      const long long nt = (long long)p.N * td * th * tw;
+      if (nt < (1ll << 30)) {
+        static const size_t cap = getenv("EFFQ_C4_GRID") ? (size_t)atoi(getenv("EFFQ_C4_GRID")) : 512;   // 2 workgroups per CU
+        size_t grid = (size_t)nt < cap ? (size_t)nt : cap;
+        if (grid > max_blocks) grid = max_blocks;
+        if (p.SD == 2)
+          hipLaunchKernelGGL(k_conv3d_c4h<2>, dim3((unsigned)grid), dim3(256), 0, st, p, td, th, tw, (int)nt);
+        else
+          hipLaunchKernelGGL(k_conv3d_c4h<1>, dim3((unsigned)grid), dim3(256), 0, st, p, td, th, tw, (int)nt);
+        return EFFQ_OK;
+      }
+    }
+  }
   if (kind == 1) {
     size_t grid = ((size_t)p.ntiles + 3) / 4;
     static const size_t cap = getenv("EFFQ_C4_GRID") ? (size_t)atoi(getenv("EFFQ_C4_GRID")) : 512;   // tuning aid

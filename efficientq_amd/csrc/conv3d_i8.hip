@@ -1124,8 +1124,10 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
   // and loss then serialise (32-channel layers: 0.104 ms per prox solve in situ against 0.046 with 15 slots free (grid 497; 482 workgroups measured worse again),
   // 1222 -> 1190 ms per calibration).  The grid is trimmed to equal runs of tiles.  EFFQ_I8_RESERVE overrides (tuning aid).
   static const int reserve = getenv("EFFQ_I8_RESERVE") ? atoi(getenv("EFFQ_I8_RESERVE")) : 15;
-  if (reserve > 0 && gx * ny > 2 * reserve) {
-    int g0 = gx - (reserve + ny - 1) / ny;
+  static const int reserve_wide = getenv("EFFQ_I8_RESERVE_WIDE") ? atoi(getenv("EFFQ_I8_RESERVE_WIDE")) : -1;   // tuning aid
+  const int rsv = (g->C1 >= 128 && reserve_wide >= 0) ? reserve_wide : reserve;
+  if (rsv > 0 && gx * ny > 2 * rsv) {
+    int g0 = gx - (rsv + ny - 1) / ny;
     const int per = (p.ntiles + g0 - 1) / g0;
     gx = (p.ntiles + per - 1) / per;
   }

@@ -63,6 +63,56 @@ __device__ __forceinline__ double disc64_fast(double x, double alpha, double ral
   return disc64(x, alpha, lo, hi, d, idx);
 }
 
+// Statistics of one fixed-point pass without per-value fp64 arithmetic beyond one multiply-add: b = r d + lo depends on
+// the level index r alone, so  sum b x = d sum(r x) + lo sum(x)  and  sum b^2 = d^2 sum(r^2) + 2 d lo sum(r) + lo^2 n,
+// with sum(r), sum(r^2) exact integers and r x exact in fp64.  r comes from an fp32 evaluation of u = (x/alpha - lo)/d
+// (error <= 3e-5 at 256 levels), accepted unless u lies within 2e-4 of a rounding boundary, where the reference's own
+// fp64 arithmetic (disc64) decides: the level indices are exactly the reference's.
+// four doubles of scratch in the tail of the reduction workspace (after the ticket and the cooperative kernel's two
+// counter words at +64 / +68): the raw totals of a level-statistics pass before level_finish
+__device__ __forceinline__ double* level_scratch(double* partials) {
+  return reinterpret_cast<double*>(reinterpret_cast<char*>(partials) + sizeof(double) * RED_MAX_BLOCKS * RED_SLOTS + 128);
+}
+struct LevelStats {
+  double arx, sx;          // sum r x, sum x (sx only when lo != 0)
+  long long sr, sr2;       // sum r, sum r^2
+};
+struct LevelConsts {
+  float c1, c0, lmax;
+  double alpha, lo, hi, d;
+  bool need_sx;
+};
+__device__ __forceinline__ LevelConsts level_consts(double alpha, double lo, double hi, double d) {
+  LevelConsts c;
+  const double rd = 1.0 / d;
+  c.c1 = (float)((1.0 / alpha) * rd);
+  c.c0 = (float)(-lo * rd);
+  c.lmax = (float)rint((hi - lo) * rd);
+  c.alpha = alpha; c.lo = lo; c.hi = hi; c.d = d;
+  c.need_sx = lo != 0.0;
+  return c;
+}
+__device__ __forceinline__ void level_accum(float xf, const LevelConsts& c, LevelStats& a) {
+  float u = __builtin_fmaf(xf, c.c1, c.c0);
+  u = fminf(fmaxf(u, 0.0f), c.lmax);
+  float rf = rintf(u);
+  if (!(fabsf(u - rf) < 0.4998f)) {
+    double r;
+    disc64((double)xf, c.alpha, c.lo, c.hi, c.d, &r);
+    rf = (float)r;
+  }
+  const int ri = (int)rf;
+  a.sr += ri;
+  a.sr2 += ri * ri;
+  a.arx = __builtin_fma((double)rf, (double)xf, a.arx);
+  if (c.need_sx) a.sx += (double)xf;
+}
+// [sum r x, sum r, sum r^2, sum x] over n values -> [sum b x, sum b b]
+__device__ __forceinline__ void level_finish(const double* t4, size_t n, double lo, double d, double* out2) {
+  out2[0] = d * t4[0] + lo * t4[3];
+  out2[1] = (d * d * t4[2] + 2.0 * d * lo * t4[1]) + lo * lo * (double)n;
+}
+
 __global__ __launch_bounds__(TPB) void k_quant_dequant_f32(const float* __restrict__ x,
                                                            const float* __restrict__ alpha_dev, float lo,
                                                            float hi, float d, float* __restrict__ y,
@@ -135,30 +185,26 @@ __global__ __launch_bounds__(TPB) void k_reduce(const float* __restrict__ x, siz
                                                 const double* __restrict__ alpha_dev, double lo, double hi,
                                                 double d, const int32_t* __restrict__ done_flag,
                                                 double* partials, unsigned int* ticket, double* out) {
-  constexpr int NS = (MODE == 1) ? 3 : 2;
+  constexpr int NS = (MODE == 1) ? 3 : (MODE == 2) ? 4 : 2;
   __shared__ double smem[NS * 16];
   __shared__ int s_last;
   if (MODE == 2 && done_flag != nullptr && *done_flag != 0) return;  // uniform across the grid
   double acc[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = 0.0;
-  double alpha = 1.0;
-  if (MODE == 2) alpha = *alpha_dev;
-  const double ralpha = 1.0 / alpha, rd = (MODE == 2) ? 1.0 / d : 1.0;
+  LevelStats ls = {0.0, 0.0, 0, 0};
+  LevelConsts lc = level_consts((MODE == 2) ? *alpha_dev : 1.0, lo, hi, (MODE == 2) ? d : 1.0);
   const size_t nv = n / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   auto body = [&](float xf) {
-    double v = (double)xf;
     if (MODE == 0) {
-      acc[0] += fabs(v);
+      acc[0] += fabs((double)xf);
     } else if (MODE == 1) {
+      const double v = (double)xf;
       acc[0] += v;
       acc[1] += v * v;
     } else {
-      double r;
-      double b = disc64_fast(v, alpha, ralpha, lo, hi, d, rd, &r);
-      acc[0] += b * v;
-      acc[1] += b * b;
+      level_accum(xf, lc, ls);
     }
   };
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
@@ -171,8 +217,13 @@ __global__ __launch_bounds__(TPB) void k_reduce(const float* __restrict__ x, siz
   for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) body(x[i]);
   if (MODE != 2) {
     if (blockIdx.x == 0 && threadIdx.x == 0) acc[NS - 1] = (double)n;
+    grid_sum_finish<NS>(acc, partials, ticket, out, smem, &s_last);
+  } else {
+    acc[0] = ls.arx; acc[1] = (double)ls.sr; acc[2] = (double)ls.sr2; acc[NS - 1] = ls.sx;
+    double* t4 = level_scratch(partials);
+    grid_sum_finish<NS>(acc, partials, ticket, t4, smem, &s_last);
+    if (s_last && threadIdx.x == 0) level_finish(t4, n, lo, d, out);
   }
-  grid_sum_finish<NS>(acc, partials, ticket, out, smem, &s_last);
 }
 
 
@@ -182,33 +233,27 @@ __global__ __launch_bounds__(TPB) void k_reduce(const float* __restrict__ x, siz
 __global__ __launch_bounds__(TPB) void k_fp_iter(const float* __restrict__ x, size_t n, effq_fp_state* st, double lo,
                                                  double hi, double d, double tol, int max_iter, double* partials,
                                                  unsigned int* ticket) {
-  __shared__ double smem[2 * 16];
+  __shared__ double smem[4 * 16];
   __shared__ int s_last;
   if (st->done != 0) return;  // uniform across the grid
   const double alpha = st->alpha;
-  const double ralpha = 1.0 / alpha, rd = 1.0 / d;
-  double acc[2] = {0.0, 0.0};
+  const LevelConsts lc = level_consts(alpha, lo, hi, d);
+  LevelStats ls = {0.0, 0.0, 0, 0};
   const size_t nv = n / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      double r;
-      const double b = disc64_fast((double)e[k], alpha, ralpha, lo, hi, d, rd, &r);
-      acc[0] += b * (double)e[k];
-      acc[1] += b * b;
-    }
+    level_accum(v.x, lc, ls);
+    level_accum(v.y, lc, ls);
+    level_accum(v.z, lc, ls);
+    level_accum(v.w, lc, ls);
   }
-  for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    double r;
-    const double b = disc64_fast((double)x[i], alpha, ralpha, lo, hi, d, rd, &r);
-    acc[0] += b * (double)x[i];
-    acc[1] += b * b;
-  }
-  // the finishing block writes the sums into st->sums, then applies the update
-  grid_sum_finish<2>(acc, partials, ticket, st->sums, smem, &s_last);
+  for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) level_accum(x[i], lc, ls);
+  double acc[4] = {ls.arx, (double)ls.sr, (double)ls.sr2, ls.sx};
+  double* t4 = level_scratch(partials);
+  grid_sum_finish<4>(acc, partials, ticket, t4, smem, &s_last);
+  if (s_last && threadIdx.x == 0) level_finish(t4, n, lo, d, st->sums);
+  // the finishing block has written the sums into st->sums; it then applies the update
   if (s_last && threadIdx.x == 0) {
     const double a_new = st->sums[0] / st->sums[1];
     st->alpha_prev = alpha;
