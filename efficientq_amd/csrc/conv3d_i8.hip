@@ -874,6 +874,157 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
                      gridDim.x * gridDim.y);
 }
 
+// ---- 64 -> 64 channels with the weights in LDS ------------------------------------------------------------------------
+// k_conv3d_i8<2> keeps the 54 B operands of a wave in 216 registers: one workgroup of 4 waves per CU, nothing to hide the
+// halo staging, the barriers and the transposed epilogue behind (0.122 ms for 16 x 32^3 voxels: 17 % of the HBM stream,
+// 5x its MFMA time).  Here ALL weights (64 x 64 x 27 bytes = 108 KB, packed [tap][group][k half][out channel][16 B]) sit in
+// LDS beside the 6 x 6 x 10 halo tile (31.5 KB): one workgroup of 8 waves per CU - wave w owns d-plane w & 3 and output
+// channels 32 (w >> 2) .. +31 of a 4 x 4 x 8 tile - with ~100 registers per wave, targets read in MFMA layout (no
+// transpose through LDS), two tiles of prefetch in flight (register sets A / B) and fp32 per-tile sums as in k_conv3d_i8l2e.
+// Tile-divisible volumes only (every shape of the shipped recipes); other shapes keep k_conv3d_i8<2>.
+constexpr int W64_WLB = 27 * 2 * 2 * 64 * 16;                                  // 110592 bytes of weights
+constexpr int W64_VS = 80, W64_HALOB = I_NH * W64_VS + I_HD * I_HH * halo_row_pad(2);
+__global__ __launch_bounds__(512, 1) void k_conv3d_i8w(ConvI8Params p) {
+  constexpr int VS = W64_VS, PADB = halo_row_pad(2);
+  constexpr int NSLOT = I_NH * 4;                   // 16-byte pieces of the halo tile (64 channels = 4 pieces)
+  constexpr int NHL = (NSLOT + 511) / 512;          // 3
+  extern __shared__ __attribute__((aligned(16))) int8_t dyn_lds[];
+  int8_t* wl = dyn_lds;
+  int8_t* halo = dyn_lds + W64_WLB;
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int plane = wid & 3, och = 32 * (wid >> 2);
+  const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per;
+  const int t_end = (t_begin + per < p.ntiles) ? t_begin + per : p.ntiles;
+
+  for (int u = tid; u < W64_WLB / 16; u += 512)
+    reinterpret_cast<v4i*>(wl)[u] = reinterpret_cast<const v4i*>(p.wq)[u];
+  lds_barrier();
+  const float scale = (float)((double)(*p.act_alpha) * (double)(float)p.wstate->alpha * p.inv_levels);
+  const float bv = (p.bias != nullptr) ? p.bias[och + li] : 0.0f;
+
+  int hcd[NHL], hch[NHL], hcw[NHL], hlds[NHL];
+  long long hrel[NHL];
+#pragma unroll
+  for (int k = 0; k < NHL; ++k) {
+    const int u = tid + k * 512;
+    const bool live = u < NSLOT;
+    const int vox = live ? (u >> 2) : 0, part = u & 3;
+    hcw[k] = vox % I_HW;
+    const int t2 = vox / I_HW;
+    hch[k] = t2 % I_HH;
+    hcd[k] = t2 / I_HH;
+    hlds[k] = live ? vox * VS + t2 * PADB + part * 16 : -1;
+    hrel[k] = (((long long)hcd[k] * p.H + hch[k]) * p.W + hcw[k]) * 64 + part * 16;
+  }
+  int yrel[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) yrel[r] = (((r >> 2) * p.OW) + (r & 3) + 4 * lh) * p.C2 + och + li;
+
+  struct Regs {
+    v4i h[NHL];
+    float y[16];
+    unsigned hmask;
+  };
+  auto fetch = [&](int tile, Regs& R) {
+    int t = tile;
+    const int ow0 = (t % p.tiles_w) * ITW;
+    t /= p.tiles_w;
+    const int oh0 = (t % p.tiles_h) * ITH;
+    t /= p.tiles_h;
+    const int od0 = (t % p.tiles_d) * ITD;
+    const int n = t / p.tiles_d;
+    const int id0 = od0 - p.PD, ih0 = oh0 - p.PH, iw0 = ow0 - p.PW;
+    const bool interior = id0 >= 0 && id0 + I_HD <= p.D && ih0 >= 0 && ih0 + I_HH <= p.H && iw0 >= 0 && iw0 + I_HW <= p.W;
+    if (interior) {                       // uniform over the workgroup
+      const int8_t* hb = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * 64;
+#pragma unroll
+      for (int k = 0; k < NHL; ++k) R.h[k] = *reinterpret_cast<const v4i*>(hb + ((hlds[k] >= 0) ? hrel[k] : 0));
+      R.hmask = 0xffffffffu;
+    } else {
+      const size_t nbase = (size_t)n * p.D;
+      unsigned hm = 0;
+#pragma unroll
+      for (int k = 0; k < NHL; ++k) {
+        const int id = id0 + hcd[k], ih = ih0 + hch[k], iw = iw0 + hcw[k];
+        const bool ok = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        const int cd = min(max(id, 0), p.D - 1), chh = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
+        hm |= (ok ? 1u : 0u) << k;
+        R.h[k] = *reinterpret_cast<const v4i*>(p.x + (((nbase + cd) * p.H + chh) * p.W + cw) * 64 + ((tid + k * 512) & 3) * 16);
+      }
+      R.hmask = hm;
+    }
+    const float* yb = p.y + ((((long long)n * p.OD + od0 + plane) * p.OH + oh0) * p.OW + ow0) * p.C2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R.y[r] = yb[yrel[r]];
+  };
+
+  const int hrow = plane * I_HH + (li >> 3);
+  const int hb0 = (hrow * I_HW + (li & 7)) * VS + hrow * PADB + 16 * lh;
+  const int8_t* wlane = wl + ((size_t)lh * 64 + och + li) * 16;        // + (tap * 2 + g) * 2 * 64 * 16 per step
+  double l0 = 0.0;
+  auto body = [&](int tile, Regs& X, bool more) {
+    lds_barrier();
+    if (X.hmask == 0xffffffffu) {
+#pragma unroll
+      for (int k = 0; k < NHL; ++k)
+        if (hlds[k] >= 0) *reinterpret_cast<v4i*>(&halo[hlds[k]]) = X.h[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NHL; ++k) {
+        const v4i val = ((X.hmask >> k) & 1u) ? X.h[k] : v4i{0, 0, 0, 0};
+        if (hlds[k] >= 0) *reinterpret_cast<v4i*>(&halo[hlds[k]]) = val;
+      }
+    }
+    float ycur[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ycur[r] = X.y[r];
+    lds_barrier();
+    fetch(more ? tile + 2 : tile, X);
+    __builtin_amdgcn_sched_barrier(0);
+    v16i acc0, acc1;                       // one chain per channel group
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const int toff = ((kd * I_HH + kh) * I_HW + kw) * VS + (kd * I_HH + kh) * PADB;
+      const v4i a0 = *reinterpret_cast<const v4i*>(halo + hb0 + toff);
+      const v4i a1 = *reinterpret_cast<const v4i*>(halo + hb0 + toff + 32);
+      const v4i b0 = *reinterpret_cast<const v4i*>(wlane + (size_t)(tap * 2 + 0) * 2 * 64 * 16);
+      const v4i b1 = *reinterpret_cast<const v4i*>(wlane + (size_t)(tap * 2 + 1) * 2 * 64 * 16);
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc1, 0, 0, 0);
+    }
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = ((float)(acc0[r] + acc1[r]) * scale + bv) - ycur[r];
+      s[r & 3] = __builtin_fmaf(d, d, s[r & 3]);
+    }
+    l0 += (double)((s[0] + s[1]) + (s[2] + s[3]));
+  };
+
+  Regs A, B;
+#pragma unroll
+  for (int k = 0; k < NHL; ++k) A.h[k] = B.h[k] = v4i{0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) A.y[r] = B.y[r] = 0.0f;
+  A.hmask = B.hmask = 0;
+  if (t_begin < t_end) fetch(t_begin, A);
+  if (t_begin + 1 < t_end) fetch(t_begin + 1, B);
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    body(tile, A, tile + 2 < t_end);
+    if (tile + 1 < t_end) body(tile + 1, B, tile + 3 < t_end);
+  }
+  double v[2] = {l0, l0};
+  grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
+}
+
 // ---- 32 channels, NB iterates per pass ---------------------------------------------------------------------------
 // The per-iteration loss of the 32-channel layers is bound by the stream of fp32 targets (128 B per voxel against 32 B
 // of level ids), not by the contraction, and the loss of an iterate is only needed when the best one is picked after
@@ -1137,6 +1288,7 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
   if (gx > p.ntiles) gx = p.ntiles;
   pl->grid = dim3((unsigned)gx, (unsigned)ny, 1);
   pl->nblk = (size_t)gx * ny;
+  if (pl->nblk < 256) pl->nblk = 256;      // k_conv3d_i8w runs one workgroup per CU whatever the plan above says
   pl->wq_bytes = (size_t)27 * p.c2p * p.C1;
   return EFFQ_OK;
 }
@@ -1270,6 +1422,25 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
   hipStream_t st = as_stream(stream);
   // (the ticket of the last-block reduction is left at zero by the kernel that used it: the caller zero-fills
   //  the workspace once, effq_hip.h)
+  static const bool w64_off = getenv("EFFQ_I8W") != nullptr && atoi(getenv("EFFQ_I8W")) == 0;      // A/B switch
+  if (p.C1 == 64 && p.C2 == 64 && !w64_off && !i8_stream64() && p.OD % ITD == 0 && p.OH % ITH == 0 && p.OW % ITW == 0) {
+    size_t nb = (pl.wq_bytes + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_pack_weight_i8g, dim3((unsigned)nb), dim3(256), 0, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
+    const size_t lds = (size_t)W64_WLB + W64_HALOB;
+    static bool attr_set = false;
+    if (!attr_set) {
+      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_i8w), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+      attr_set = true;
+    }
+    int gx = 256;                           // one workgroup per CU (LDS); pl.nblk = 256 partial slots
+    if (gx > p.ntiles) gx = p.ntiles;
+    if ((size_t)gx > pl.nblk) gx = (int)pl.nblk;
+    hipLaunchKernelGGL(k_conv3d_i8w, dim3((unsigned)gx), dim3(512), lds, st, p);
+    EFFQ_LAUNCH_CHECK();
+    return EFFQ_OK;
+  }
   {
     size_t nb = (pl.wq_bytes + 255) / 256;
     if (nb > 2048) nb = 2048;
