@@ -15,6 +15,14 @@
 #include "common.h"
 
 extern "C" {
+int effq_project_dual_next(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
+                           float* dual, float dual_div, int8_t* Gq_out, size_t n, int32_t* err_flag_dev, float* Bm,
+                           const float* B0, const float* W0, int nwrow, int nb0, int ldb, double rho_next, double eta,
+                           void* stream);
+float* effq_prox_bm(void* ws, int c2, int n, int* ldb);
+int effq_prox_solve_prebuilt(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
+                             const float* dual, int c2, int n, int has_bias, double rho, double eta, float* wstar,
+                             float* bstar, void* ws, size_t ws_bytes, void* stream);
 int effq_project_dual_checked(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
                               float* dual, float dual_div, int8_t* Gq_out, size_t n, int32_t* err_flag_dev,
                               void* stream);   // quant_reduce.hip (internal)
@@ -289,6 +297,11 @@ int effq_admm_run(const effq_admm_run_args* a) {
 
   double rho = a->rho;
   int cur = -1;     // index into plan.rho of the inverse in use
+  static const bool fuse_off = getenv("EFFQ_FUSE_BUILD") != nullptr && atoi(getenv("EFFQ_FUSE_BUILD")) == 0;   // A/B switch
+  const bool fuse_build = !fuse_off && !pair;
+  int bm_ld = 0;
+  float* bm = effq_prox_bm(a->prox_ws, c2, n, &bm_ld);
+  bool bm_ready = false;
   const float* Ainv = nullptr;
   for (int i = 0; i < a->iters; ++i) {
     const bool use_shift = plan.shifted_first && i == 0;
@@ -314,6 +327,9 @@ int effq_admm_run(const effq_admm_run_args* a) {
       ADMM_RC(effq_prox_solve_shifted(a->B0, a->ainv_pool, a->W0, a->b0, G_prev, a->dual, c2, n, has_b, rho, a->eta,
                                       plan.rho[1], shift_terms(rho, a->eta, plan.rho[1]), a->wstar, bstar, a->prox_ws,
                                       a->prox_ws_bytes, s_main));
+    else if (bm_ready)
+      ADMM_RC(effq_prox_solve_prebuilt(a->B0, Ainv, a->W0, a->b0, G_prev, a->dual, c2, n, has_b, rho, a->eta, a->wstar,
+                                       bstar, a->prox_ws, a->prox_ws_bytes, s_main));
     else
       ADMM_RC(effq_prox_solve(a->B0, Ainv, a->W0, a->b0, G_prev, a->dual, c2, n, has_b, rho, a->eta, a->wstar, bstar,
                               a->prox_ws, a->prox_ws_bytes, s_main));
@@ -330,8 +346,21 @@ int effq_admm_run(const effq_admm_run_args* a) {
                                     a->red_ws, s_main));
     p_fp.close();
     ProfScope p_pr(prof, PROF_PROJECT, i, a, s_main);
-    ADMM_RC(effq_project_dual_checked(a->v, a->wstar, st, a->w_levels, G, a->dual, dual_div, Gq, nw, a->err_flag,
-                                      s_main));
+    {
+      // the projection also leaves the right-hand side of the NEXT prox solve in the prox workspace (one launch per
+      // iteration less on the critical path); the first solve of the layer builds Bm itself (bias column, padding)
+      double rho_next = rho;
+      if (i % a->rho_period == 0) rho_next = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
+      if (fuse_build && i + 1 < a->iters) {
+        ADMM_RC(effq_project_dual_next(a->v, a->wstar, st, a->w_levels, G, a->dual, dual_div, Gq, nw, a->err_flag, bm,
+                                       a->B0, a->W0, n - has_b, n, bm_ld, rho_next, a->eta, s_main));
+        bm_ready = true;
+      } else {
+        ADMM_RC(effq_project_dual_checked(a->v, a->wstar, st, a->w_levels, G, a->dual, dual_div, Gq, nw, a->err_flag,
+                                          s_main));
+        bm_ready = false;
+      }
+    }
     p_pr.close();
     // ---- the loss of this iterate (loss stream); 32 -> 32 layers evaluate two iterates per pass ----
     const bool last = (i == a->iters - 1);

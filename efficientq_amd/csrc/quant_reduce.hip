@@ -625,11 +625,21 @@ __global__ __launch_bounds__(TPB) void k_presum(const float* __restrict__ a, con
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) o[i] = a[i] + b[i];
 }
 
+// Optional extra output of the projection: Bm = B0 + eta [W0|b0] + rho (G - dual) for the next iteration's prox solve,
+// element for element what k_build_b4 (solve.hip) computes - one launch per ADMM iteration less.  The bias column and the
+// zero padding of Bm do not depend on the iterate: they stay as the first build of the layer left them.
+struct ProjNext {
+  float* Bm;
+  const float* B0;
+  const float* W0;
+  int nwrow, n, ldb;       // weights per output channel, row length of B0, row length of Bm
+  float rho, eta;
+};
 __global__ __launch_bounds__(TPB) void k_project_dual(const float* __restrict__ v, const float* __restrict__ wstar,
                                                       const effq_fp_state* __restrict__ st, double d,
                                                       float* __restrict__ G, float* __restrict__ dual,
                                                       float dual_div, int8_t* __restrict__ Gq, int lm1, size_t n,
-                                                      int32_t* __restrict__ err_flag) {
+                                                      int32_t* __restrict__ err_flag, ProjNext nx) {
   __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
 
   // (optional) the convergence check of the fixed point that produced `st`, folded in to save a launch
@@ -648,6 +658,12 @@ __global__ __launch_bounds__(TPB) void k_project_dual(const float* __restrict__ 
     float du = (wstar[i] - g) + dual[i];        // EfficientQConv.py:111
     if (dual_div != 1.0f) du = du / dual_div;   // "dual /= 2" or "dual /= rho_m/rho" (:131-136)
     dual[i] = du;
+    if (nx.Bm != nullptr) {                     // right-hand side of the NEXT prox solve (k_build_b4's arithmetic)
+      const size_t r = i / (size_t)nx.nwrow, k = i - r * (size_t)nx.nwrow;
+      float bv = nx.B0[r * (size_t)nx.n + k] + nx.eta * nx.W0[i];
+      bv = bv + nx.rho * (g - du);
+      nx.Bm[r * (size_t)nx.ldb + k] = bv;
+    }
   }
 }
 
@@ -1003,8 +1019,29 @@ int effq_project_dual_checked(const float* v, const float* wstar, const effq_fp_
   EFFQ_CHECK_ARG(Gq_out == nullptr || levels <= 256);
   if (n == 0) return EFFQ_OK;
   const double d = 2.0 / (double)(levels - 1);
+  ProjNext nx;
+  memset(&nx, 0, sizeof(nx));
   hipLaunchKernelGGL(k_project_dual, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
-                     G, dual, dual_div, Gq_out, levels - 1, n, err_flag_dev);
+                     G, dual, dual_div, Gq_out, levels - 1, n, err_flag_dev, nx);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+// internal (admm_run.hip): the projection that also leaves the right-hand side of the next prox solve in Bm
+int effq_project_dual_next(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
+                           float* dual, float dual_div, int8_t* Gq_out, size_t n, int32_t* err_flag_dev, float* Bm,
+                           const float* B0, const float* W0, int nwrow, int nb0, int ldb, double rho_next, double eta,
+                           void* stream) {
+  EFFQ_CHECK_ARG(v && wstar && state_dev && G && dual && levels >= 2 && dual_div > 0.0f);
+  EFFQ_CHECK_ARG(Gq_out == nullptr || levels <= 256);
+  EFFQ_CHECK_ARG(Bm && B0 && W0 && nwrow > 0 && nb0 >= nwrow && ldb >= nb0 && (n % (size_t)nwrow) == 0);
+  if (n == 0) return EFFQ_OK;
+  const double d = 2.0 / (double)(levels - 1);
+  ProjNext nx;
+  nx.Bm = Bm; nx.B0 = B0; nx.W0 = W0; nx.nwrow = nwrow; nx.n = nb0; nx.ldb = ldb;
+  nx.rho = (float)rho_next; nx.eta = (float)eta;
+  hipLaunchKernelGGL(k_project_dual, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
+                     G, dual, dual_div, Gq_out, levels - 1, n, err_flag_dev, nx);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

@@ -593,7 +593,8 @@ size_t effq_prox_ws_bytes(int c2, int n) {
 
 static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
                            const float* dual, int c2, int n, int has_bias, double rho, double eta, double shift,
-                           int nterms, float* wstar, float* bstar, void* ws, size_t ws_bytes, void* stream) {
+                           int nterms, float* wstar, float* bstar, void* ws, size_t ws_bytes, void* stream,
+                           bool prebuilt = false) {
   EFFQ_CHECK_ARG(B0 && Ainv && W0 && G && dual && wstar && ws && c2 > 0 && n > 0 && nterms >= 1);
   EFFQ_CHECK_ARG(!has_bias || (b0 != nullptr && bstar != nullptr));
   if (ws_bytes < effq_prox_ws_bytes(c2, n)) {
@@ -608,7 +609,7 @@ static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, 
   float* part = Bm + (size_t)c2p * ldb;
   hipStream_t st = as_stream(stream);
   for (int term = 0; term < nterms; ++term) {
-    {
+    if (!(prebuilt && term == 0)) {     // prebuilt: the previous projection already left Bm (effq_project_dual_next)
       const int nw = n - (has_bias ? 1 : 0);
       if ((nw % 4) == 0) {
         const unsigned bx = (unsigned)((ldb / 4 + 255) / 256);
@@ -658,6 +659,19 @@ int effq_prox_solve(const float* B0, const float* Ainv, const float* W0, const f
                     void* ws, size_t ws_bytes, void* stream) {
   return prox_solve_impl(B0, Ainv, W0, b0, G, dual, c2, n, has_bias, rho, eta, 0.0, 1, wstar, bstar, ws, ws_bytes,
                          stream);
+}
+
+// internal (admm_run.hip): Bm = the start of the prox workspace, its row length; the solve on a Bm that
+// effq_project_dual_next has already written
+float* effq_prox_bm(void* ws, int c2, int n, int* ldb) {
+  *ldb = prox_plan(c2, n).ldb;
+  return reinterpret_cast<float*>(ws);
+}
+int effq_prox_solve_prebuilt(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
+                             const float* dual, int c2, int n, int has_bias, double rho, double eta, float* wstar,
+                             float* bstar, void* ws, size_t ws_bytes, void* stream) {
+  return prox_solve_impl(B0, Ainv, W0, b0, G, dual, c2, n, has_bias, rho, eta, 0.0, 1, wstar, bstar, ws, ws_bytes,
+                         stream, true);
 }
 
 int effq_prox_solve_shifted(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
