@@ -63,20 +63,31 @@ __global__ __launch_bounds__(256) void k_pack_weight_i8(const int8_t* __restrict
 // MFMA is a 512-byte contiguous run per lane half (coalesced 16-byte loads straight from L2).
 __global__ __launch_bounds__(256) void k_pack_weight_i8g(const int8_t* __restrict__ Gq, int8_t* __restrict__ wq, int C1,
                                                          int C2, int T, int c2p) {
-  const size_t total = (size_t)T * c2p * C1;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const int CG = C1 / 32;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    const int b = (int)(e & 15);
-    size_t r = e >> 4;
-    const int j = (int)(r % c2p);
-    r /= c2p;
-    const int h = (int)(r & 1);
+  // one 16-byte cell (tap, g, h, j) per thread: 32-bit index arithmetic once per 16 bytes, one 16-byte store
+  const unsigned cells = (unsigned)T * (unsigned)c2p * (unsigned)(C1 / 16);
+  const unsigned stride = gridDim.x * blockDim.x;
+  const unsigned CG = (unsigned)C1 / 32u;
+  for (unsigned r0 = blockIdx.x * blockDim.x + threadIdx.x; r0 < cells; r0 += stride) {
+    unsigned r = r0;
+    const unsigned j = r % (unsigned)c2p;
+    r /= (unsigned)c2p;
+    const unsigned h = r & 1u;
     r >>= 1;
-    const int g = (int)(r % CG);
-    const int tap = (int)(r / CG);
-    const int c = 32 * g + 16 * h + b;
-    wq[e] = (j < C2) ? Gq[((size_t)j * C1 + c) * T + tap] : (int8_t)0;
+    const unsigned g = r % CG;
+    const unsigned tap = r / CG;
+    const unsigned c0 = 32u * g + 16u * h;
+    v4i out = {0, 0, 0, 0};
+    if (j < (unsigned)C2) {
+      const int8_t* src = Gq + ((size_t)j * C1 + c0) * T + tap;       // 16 channels, T bytes apart
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned wv = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) wv |= (unsigned)(unsigned char)src[(size_t)(4 * q + b) * T] << (8 * b);
+        out[q] = (int)wv;
+      }
+    }
+    *reinterpret_cast<v4i*>(wq + (size_t)r0 * 16) = out;
   }
 }
 

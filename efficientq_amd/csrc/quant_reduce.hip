@@ -667,6 +667,73 @@ __global__ __launch_bounds__(TPB) void k_project_dual(const float* __restrict__ 
   }
 }
 
+// Four consecutive weights per thread (weight rows that are a multiple of 4 long: every layer of the shipped nets): 16-byte
+// accesses, one (row, column) split per thread with 32-bit arithmetic, and the level index from the fp32 evaluation of
+// level_accum (the reference's fp64 arithmetic decides within 2e-4 of a rounding boundary: indices are exact).
+__global__ __launch_bounds__(TPB) void k_project_dual4(const float* __restrict__ v, const float* __restrict__ wstar,
+                                                       const effq_fp_state* __restrict__ st, double d,
+                                                       float* __restrict__ G, float* __restrict__ dual,
+                                                       float dual_div, int8_t* __restrict__ Gq, int lm1, unsigned n4,
+                                                       int32_t* __restrict__ err_flag, ProjNext nx) {
+  __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+  if (err_flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && st->done != 1) *err_flag = (st->done == 2) ? 2 : 3;
+  const double alpha = st->alpha;
+  const float alpha32 = (float)alpha;
+  const LevelConsts lc = level_consts(alpha, -1.0, 1.0, d);
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+    const size_t i = (size_t)q * 4;
+    const float4 vv = *reinterpret_cast<const float4*>(v + i), ww = *reinterpret_cast<const float4*>(wstar + i),
+                 dd = *reinterpret_cast<const float4*>(dual + i);
+    const float ve[4] = {vv.x, vv.y, vv.z, vv.w}, we[4] = {ww.x, ww.y, ww.z, ww.w}, de[4] = {dd.x, dd.y, dd.z, dd.w};
+    float ge[4], du[4];
+    int ri[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float u = __builtin_fmaf(ve[e], lc.c1, lc.c0);
+      u = fminf(fmaxf(u, 0.0f), lc.lmax);
+      float rf = rintf(u);
+      if (!(fabsf(u - rf) < 0.4998f)) {
+        double r;
+        disc64((double)ve[e], alpha, -1.0, 1.0, d, &r);
+        rf = (float)r;
+      }
+      ri[e] = (int)rf;
+      const float b = (float)((double)rf * d + -1.0);       // disc64's r * d + lo
+      ge[e] = alpha32 * b;
+      float t = (we[e] - ge[e]) + de[e];                    // EfficientQConv.py:111
+      if (dual_div != 1.0f) t = t / dual_div;               // "dual /= 2" or "dual /= rho_m/rho" (:131-136)
+      du[e] = t;
+    }
+    *reinterpret_cast<float4*>(G + i) = make_float4(ge[0], ge[1], ge[2], ge[3]);
+    *reinterpret_cast<float4*>(dual + i) = make_float4(du[0], du[1], du[2], du[3]);
+    if (Gq != nullptr) {
+      char4 c;
+      if (lm1 >= 128) {
+        c = make_char4((signed char)(ri[0] - 128), (signed char)(ri[1] - 128), (signed char)(ri[2] - 128), (signed char)(ri[3] - 128));
+      } else {
+        c = make_char4((signed char)(2 * ri[0] - lm1), (signed char)(2 * ri[1] - lm1), (signed char)(2 * ri[2] - lm1),
+                       (signed char)(2 * ri[3] - lm1));
+      }
+      *reinterpret_cast<char4*>(Gq + i) = c;
+    }
+    if (nx.Bm != nullptr) {                       // right-hand side of the NEXT prox solve (k_build_b4's arithmetic)
+      const unsigned i32 = q * 4u;
+      const unsigned r = i32 / (unsigned)nx.nwrow, k = i32 - r * (unsigned)nx.nwrow;   // a group of 4 never straddles rows
+      const float* bp = nx.B0 + (size_t)r * (size_t)nx.n + k;                            // (rows of B0 are n long: unaligned)
+      const float4 w0 = *reinterpret_cast<const float4*>(nx.W0 + i);
+      const float w0e[4] = {w0.x, w0.y, w0.z, w0.w};
+      float be[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = bp[e] + nx.eta * w0e[e];
+        be[e] = t + nx.rho * (ge[e] - du[e]);
+      }
+      *reinterpret_cast<float4*>(nx.Bm + (size_t)r * (size_t)nx.ldb + k) = make_float4(be[0], be[1], be[2], be[3]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(TPB) void k_keep_best(const double* __restrict__ sqerr, double* best, int iter,
                                                    const float* __restrict__ G, const float* __restrict__ b,
                                                    float* __restrict__ bG, float* __restrict__ bb, size_t nw,
@@ -1012,6 +1079,11 @@ int effq_admm_presum(const float* wstar, const float* dual, float* v, size_t n, 
   return EFFQ_OK;
 }
 
+static bool proj_aligned(const void* a, const void* b, const void* c, const void* d, const void* q) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+           reinterpret_cast<uintptr_t>(d)) & 15) == 0 && (reinterpret_cast<uintptr_t>(q) & 3) == 0;
+}
+
 int effq_project_dual_checked(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
                               float* dual, float dual_div, int8_t* Gq_out, size_t n, int32_t* err_flag_dev,
                               void* stream) {
@@ -1021,8 +1093,12 @@ int effq_project_dual_checked(const float* v, const float* wstar, const effq_fp_
   const double d = 2.0 / (double)(levels - 1);
   ProjNext nx;
   memset(&nx, 0, sizeof(nx));
-  hipLaunchKernelGGL(k_project_dual, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
-                     G, dual, dual_div, Gq_out, levels - 1, n, err_flag_dev, nx);
+  if ((n % 4) == 0 && n < ((size_t)1 << 32) && proj_aligned(v, wstar, G, dual, Gq_out))
+    hipLaunchKernelGGL(k_project_dual4, dim3(stream_grid(n / 4)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
+                       G, dual, dual_div, Gq_out, levels - 1, (unsigned)(n / 4), err_flag_dev, nx);
+  else
+    hipLaunchKernelGGL(k_project_dual, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
+                       G, dual, dual_div, Gq_out, levels - 1, n, err_flag_dev, nx);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }
@@ -1040,8 +1116,13 @@ int effq_project_dual_next(const float* v, const float* wstar, const effq_fp_sta
   ProjNext nx;
   nx.Bm = Bm; nx.B0 = B0; nx.W0 = W0; nx.nwrow = nwrow; nx.n = nb0; nx.ldb = ldb;
   nx.rho = (float)rho_next; nx.eta = (float)eta;
-  hipLaunchKernelGGL(k_project_dual, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
-                     G, dual, dual_div, Gq_out, levels - 1, n, err_flag_dev, nx);
+  if ((nwrow % 4) == 0 && (ldb % 4) == 0 && n < ((size_t)1 << 32) && proj_aligned(v, wstar, G, dual, Gq_out) &&
+      (reinterpret_cast<uintptr_t>(W0) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0)
+    hipLaunchKernelGGL(k_project_dual4, dim3(stream_grid(n / 4)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
+                       G, dual, dual_div, Gq_out, levels - 1, (unsigned)(n / 4), err_flag_dev, nx);
+  else
+    hipLaunchKernelGGL(k_project_dual, dim3(stream_grid(n)), dim3(TPB), 0, as_stream(stream), v, wstar, state_dev, d,
+                       G, dual, dual_div, Gq_out, levels - 1, n, err_flag_dev, nx);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }
