@@ -284,6 +284,12 @@ CONV_CASES = [
     (32, 3, 1, 1, 0, (8, 8, 8)),        # classifier
     (64, 64, 3, 1, 1, (4, 8, 8)),       # two channel slabs
     (48, 40, 3, 1, 1, (4, 4, 8)),       # odd widths
+    (4, 32, 3, 2, 1, (24, 24, 48)),     # first layer: 3 x 3 x 3 tiles of the LDS-staged kernel, the centre one interior
+    (4, 32, 3, 2, 1, (10, 14, 18)),     # first layer, ragged output tiles (5 x 7 x 9)
+    (4, 32, 3, 1, 1, (12, 12, 24)),     # the same kernel at stride 1
+    (64, 3, 1, 1, 0, (5, 6, 7)),        # classifier kernel: 64 channels, voxel count not a multiple of its 64-voxel body
+    (128, 2, 1, 1, 0, (4, 4, 6)),
+    (256, 4, 1, 1, 0, (3, 4, 5)),
 ]
 
 
@@ -381,7 +387,10 @@ def test_single_launch_weight_fixed_point_matches_goldens(ops, gold, L):
 @pytest.mark.parametrize("c1,c2,La,Lw,sp", [(32, 32, 4, 4, (8, 8, 16)), (32, 64, 16, 16, (9, 7, 11)),
                                              (64, 64, 4, 4, (8, 8, 8)), (64, 32, 16, 4, (5, 6, 9)),
                                              (32, 32, 128, 128, (4, 4, 8)), (128, 128, 4, 4, (4, 8, 8)),
-                                             (256, 64, 16, 16, (4, 4, 8)), (128, 32, 16, 4, (5, 6, 9))])
+                                             (256, 64, 16, 16, (4, 4, 8)), (128, 32, 16, 4, (5, 6, 9)),
+                                             # 3 x 3 x 3 tiles: the centre tile takes the interior fast path
+                                             (32, 32, 4, 4, (24, 12, 24)), (64, 64, 4, 4, (12, 12, 24)),
+                                             (64, 64, 16, 16, (12, 10, 24))])     # 64 ch, not tile-divisible
 def test_exact_int_conv_step_equals_fp32_path(ops, c1, c2, La, Lw, sp):
     """conv3d_calib_step_i8 (i8 MFMA, exact int32 accumulation) against conv3d_quant_calib_step on the
     SAME quantised operands: identical loss up to the fp32 path's own rounding (<= 2e-6 relative)."""
