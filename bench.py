@@ -107,7 +107,9 @@ class OpTimer:
             _lib.check(lib.effq_prof_read(i, C.byref(r)), "effq_prof_read")
             g = r.geom
             kind = self.KIND[r.kind]
-            if kind == "loss":
+            if kind == "loss" and r.loss_kind == 4:
+                key = ("gram_loss@loop", r.c2, r.n)
+            elif kind == "loss":
                 name = {0: "conv_step", 1: "conv_step_i8", 2: "conv_step_i8s", 3: "conv_step_i8_pair"}[r.loss_kind] + "@loop"
                 key = (name, g.N, g.C1, g.C2, g.D, g.H, g.W, g.KD, g.SD)
             else:
@@ -146,6 +148,10 @@ class OpTimer:
             return ("mfma", 2.0 * n * n * V + 2.0 * c2 * n * V, PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                     f"k_gram (n={n}, {V} voxels; 2n^2V+2c2nV flop, upper triangle computed)")
         c2, n = key[1:]
+        if op == "gram_loss":
+            return ("mfma", 2.0 * c2 * n * n, PEAK_F64_MFMA_TFLOPS, "TFLOP/s",
+                    f"k_gram_loss (c2={c2}, n={n}: loss of an iterate from the unweighted Gram system, 2 c2 n^2 fp64 flop "
+                    f"on an n x n matrix instead of a pass over the voxels)")
         if op == "inverse":
             return ("mfma", 2.0 * n ** 3, PEAK_F64_MFMA_TFLOPS, "TFLOP/s", f"k_gj_* (n={n}, 2n^3 fp64 flop)")
         if op == "prox":

@@ -76,7 +76,8 @@ class AdmmRunArgs(C.Structure):
                 ("inv_ws", C.c_void_p), ("inv_ws_bytes", C.c_size_t),
                 ("inv_ws_side", C.c_void_p), ("inv_ws_side_bytes", C.c_size_t),
                 ("conv_ws", C.c_void_p), ("conv_ws_bytes", C.c_size_t),
-                ("stream_main", C.c_void_p), ("stream_loss", C.c_void_p), ("stream_side", C.c_void_p)]
+                ("stream_main", C.c_void_p), ("stream_loss", C.c_void_p), ("stream_side", C.c_void_p),
+                ("loss_Au", C.c_void_p), ("loss_Bu", C.c_void_p), ("loss_syy", C.c_void_p)]
 
 
 class ProfRecord(C.Structure):
@@ -127,6 +128,9 @@ SIGNATURES = {
     "effq_gram_i8_supported": (_I, [_GP, _I]),
     "effq_gram_i8_ws_bytes": (_SZ, [_GP, _I]),
     "effq_gram_accum_i8": (_I, [_P, _P, _GP, _I, _P, _I, _P, _P, _P, _I, _LL, _P, _P, _I, _P, _SZ, _P]),
+    "effq_gram_accum_i8_unw": (_I, [_P, _P, _GP, _I, _P, _I, _P, _P, _P, _I, _LL, _P, _P, _I, _P, _P, _P, _SZ, _P]),
+    "effq_gram_loss_ws_bytes": (_SZ, [_I]),
+    "effq_gram_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "effq_packed_bytes": (_SZ, [_SZ, _I]),
     "effq_pack_levels": (_I, [_P, _SZ, _I, _P, _P]),
     "effq_unpack_levels": (_I, [_P, _SZ, _I, _P, _P]),

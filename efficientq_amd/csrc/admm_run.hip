@@ -184,9 +184,12 @@ int effq_admm_run(const effq_admm_run_args* a) {
                  a->err_flag && a->ainv_pool && a->prox_ws && a->red_ws && a->inv_ws && a->conv_ws && a->y_fp);
   EFFQ_CHECK_ARG(a->c2 > 0 && a->n > 1 && a->iters > 0 && a->rho_period > 0 && a->w_levels >= 2 && a->w_levels <= 256);
   EFFQ_CHECK_ARG((a->has_bias != 0) == (a->b0 != nullptr) && (a->has_bias != 0) == (a->b_ring != nullptr));
-  EFFQ_CHECK_ARG(a->loss_kind >= 0 && a->loss_kind <= 2);
-  EFFQ_CHECK_ARG(a->loss_kind == 0 ? (a->xq != nullptr) : (a->xidx != nullptr && a->Gq_ring != nullptr &&
-                                                          a->act_alpha_dev != nullptr));
+  EFFQ_CHECK_ARG((a->loss_kind >= 0 && a->loss_kind <= 2) || a->loss_kind == 4);
+  if (a->loss_kind == 4)
+    EFFQ_CHECK_ARG(a->loss_Au != nullptr && a->loss_Bu != nullptr && a->loss_syy != nullptr);
+  else
+    EFFQ_CHECK_ARG(a->loss_kind == 0 ? (a->xq != nullptr) : (a->xidx != nullptr && a->Gq_ring != nullptr &&
+                                                            a->act_alpha_dev != nullptr));
   const int c2 = a->c2, n = a->n, has_b = a->has_bias ? 1 : 0;
   const size_t nw = (size_t)c2 * (size_t)(n - has_b);
   EFFQ_CHECK_ARG(nw == (size_t)a->geom.C2 * a->geom.C1 * a->geom.KD * a->geom.KH * a->geom.KW);
@@ -390,6 +393,9 @@ int effq_admm_run(const effq_admm_run_args* a) {
     else if (a->loss_kind == 2)
       ADMM_RC(conv3d_calib_step_i8s(a->xidx, Gq, bstar, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, st,
                                     a->w_levels, i == 0 ? 1 : 0, sq, a->conv_ws, a->conv_ws_bytes, s_loss));
+    else if (a->loss_kind == 4)
+      ADMM_RC(effq_gram_loss(a->loss_Au, a->loss_Bu, a->loss_syy, G, bstar, c2, n, has_b, sq, a->conv_ws, a->conv_ws_bytes,
+                             s_loss));
     else
       ADMM_RC(conv3d_quant_calib_step(a->xq, G, bstar, a->y_fp, nullptr, &a->geom, nullptr, 0, sq, nullptr, a->conv_ws,
                                       a->conv_ws_bytes, s_loss));   // unweighted MSE (quirk Q5)

@@ -318,19 +318,26 @@ __global__ __launch_bounds__(256) void k_gi_ydigits(const float* __restrict__ y,
 __global__ __launch_bounds__(256) void k_gram_i8_finish(GramI8Params p, int n, int hb, const float* __restrict__ alpha,
                                                         int act_levels, const unsigned* __restrict__ ymax_bits,
                                                         const float* __restrict__ cls_w, float* __restrict__ A0,
-                                                        float* __restrict__ B0, int accumulate) {
+                                                        float* __restrict__ B0, int accumulate, double* __restrict__ Au,
+                                                        double* __restrict__ Bu) {
   const double s = (double)alpha[0] / (double)(act_levels - 1);
   const double q = ldexp(1.0, gi_y_exponent(*ymax_bits) - 30);
   const size_t nA = (size_t)n * n, nB = (size_t)p.C2 * n;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t blk = (size_t)(GI_MB * GI_MB);
+  double unw = 0.0;
   auto S = [&](int ri, int rj) -> double {
     const int I = ri / GI_MB, J = rj / GI_MB;
     const size_t pidx = (size_t)I * p.NB - (size_t)I * (I - 1) / 2 + (J - I);
     const size_t off = pidx * blk + (size_t)(ri - I * GI_MB) * GI_MB + (rj - J * GI_MB);
     double t = 0.0;
-    for (int c = 0; c < p.ncls; ++c)
-      t += (cls_w ? (double)cls_w[c] : 1.0) * (double)p.slabs[(size_t)c * p.npairs * blk + off];
+    long long u = 0;
+    for (int c = 0; c < p.ncls; ++c) {
+      const long long sl = p.slabs[(size_t)c * p.npairs * blk + off];
+      t += (cls_w ? (double)cls_w[c] : 1.0) * (double)sl;
+      u += sl;
+    }
+    unw = (double)u;           // the same sum without the attention weights (exact integer)
     return t;
   };
   auto to_int = [&](int qq, bool& isx) {
@@ -354,17 +361,28 @@ __global__ __launch_bounds__(256) void k_gram_i8_finish(GramI8Params p, int n, i
         ri = rj;
         rj = t;
       }
-      val = 2.0 * (xa ? s : 1.0) * (xb ? s : 1.0) * S(ri, rj);
+      const double sc = (xa ? s : 1.0) * (xb ? s : 1.0);
+      val = 2.0 * sc * S(ri, rj);
       dst = A0 + e;
+      // unweighted system of the same pass, in fp64 and without the factor 2: Au = sum_v xhat xhat^T (ones row included),
+      // Bu = sum_v y xhat^T - what the loss of an iterate needs (effq_gram_loss)
+      if (Au != nullptr) Au[e] = accumulate ? Au[e] + sc * unw : sc * unw;
     } else {
       const size_t f = e - nA;
       const int c2 = (int)(f / n), b = (int)(f % n);
       bool xb;
       const int ri = to_int(b, xb);
-      double t = 0.0, w = 1.0;
-      for (int d = 0; d < 4; ++d, w *= 256.0) t += w * S(ri, p.YR0 + d * p.C2P + c2);
+      double t = 0.0, tu = 0.0, w = 1.0;
+      for (int d = 0; d < 4; ++d, w *= 256.0) {
+        t += w * S(ri, p.YR0 + d * p.C2P + c2);
+        tu += w * unw;
+      }
       val = 2.0 * q * (xb ? s : 1.0) * t;
       dst = B0 + f;
+      if (Bu != nullptr) {
+        const double vu = q * (xb ? s : 1.0) * tu;
+        Bu[f] = accumulate ? Bu[f] + vu : vu;
+      }
     }
     *dst = accumulate ? (*dst + (float)val) : (float)val;
   }
@@ -442,10 +460,11 @@ size_t effq_gram_i8_ws_bytes(const effq_geom* g, int ncls) {
   return 256 + gram_i8_slab_bytes(p) + (size_t)p.V * 4 * p.C2P + 256 + gram_i8_table_bytes(p.V, ncls) + 256;
 }
 
-int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const effq_geom* g, int has_bias,
-                       const float* act_alpha_dev, int act_levels, const int32_t* vox_list, const int32_t* chunk_cls,
-                       const float* cls_w_dev, int ncls, long long n_list, float* A0, float* B0, int accumulate,
-                       void* ws, size_t ws_bytes, void* stream) {
+int effq_gram_accum_i8_unw(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const effq_geom* g, int has_bias,
+                           const float* act_alpha_dev, int act_levels, const int32_t* vox_list, const int32_t* chunk_cls,
+                           const float* cls_w_dev, int ncls, long long n_list, float* A0, float* B0, int accumulate,
+                           double* Au, double* Bu, void* ws, size_t ws_bytes, void* stream) {
+  EFFQ_CHECK_ARG((Au == nullptr) == (Bu == nullptr));
   EFFQ_CHECK_ARG(xidx_ndhwc && y_ndhwc && g && act_alpha_dev && A0 && B0 && ws);
   EFFQ_CHECK_ARG(effq_gram_i8_supported(g, act_levels));
   if (vox_list == nullptr) {
@@ -505,9 +524,17 @@ int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const ef
   size_t nb = (tot + 255) / 256;
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(k_gram_i8_finish, dim3((unsigned)nb), dim3(256), 0, st, p, n, has_bias ? 1 : 0, act_alpha_dev,
-                     act_levels, ymax, cls_w_dev, A0, B0, accumulate);
+                     act_levels, ymax, cls_w_dev, A0, B0, accumulate, Au, Bu);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
+}
+
+int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const effq_geom* g, int has_bias,
+                       const float* act_alpha_dev, int act_levels, const int32_t* vox_list, const int32_t* chunk_cls,
+                       const float* cls_w_dev, int ncls, long long n_list, float* A0, float* B0, int accumulate,
+                       void* ws, size_t ws_bytes, void* stream) {
+  return effq_gram_accum_i8_unw(xidx_ndhwc, y_ndhwc, g, has_bias, act_alpha_dev, act_levels, vox_list, chunk_cls,
+                                cls_w_dev, ncls, n_list, A0, B0, accumulate, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -313,9 +313,10 @@ class HipOps:
 
     def gram_i8(self, xidx_ndhwc: torch.Tensor, att_cls, y_ndhwc: torch.Tensor, geom: Geom, has_bias: bool,
                 act_alpha: torch.Tensor, act_levels: int, A0: Optional[torch.Tensor] = None,
-                B0: Optional[torch.Tensor] = None):
+                B0: Optional[torch.Tensor] = None, unweighted: bool = False):
         """A0/B0 of gram() for an already quantised input, exact on the i8 matrix cores (effq_gram_accum_i8).
-        att_cls = att_classes(att)."""
+        att_cls = att_classes(att).  unweighted=True also returns (Au, Bu): the same sums without the attention weights,
+        fp64, no factor 2 - the operands of gram_loss()."""
         if xidx_ndhwc.dtype != torch.uint8 or not xidx_ndhwc.is_contiguous():
             raise _lib.EffqError("gram_i8 wants contiguous uint8 level ids")
         y = self._f32(y_ndhwc)
@@ -335,11 +336,32 @@ class HipOps:
             B0 = torch.empty(geom.C2, n, dtype=torch.float32, device=self.device)
         al = self._f32(act_alpha.reshape(1))
         ws = self._workspace("gram_i8", self.lib.effq_gram_i8_ws_bytes(C.byref(geom), int(ncls)))
-        check(self.lib.effq_gram_accum_i8(_ptr(xidx_ndhwc), _ptr(y), C.byref(geom), int(has_bias), _ptr(al),
-                                          int(act_levels), _ptr(lst), _ptr(chunk_cls), _ptr(cls_w), int(ncls),
-                                          0 if lst is None else int(lst.numel()), _ptr(A0), _ptr(B0), acc, _ptr(ws),
-                                          ws.numel(), self.stream), "effq_gram_accum_i8")
-        return A0, B0
+        Au = Bu = None
+        if unweighted:
+            if acc:
+                raise _lib.EffqError("gram_i8: the unweighted system is not accumulated across calls here")
+            Au = torch.empty(n, n, dtype=torch.float64, device=self.device)
+            Bu = torch.empty(geom.C2, n, dtype=torch.float64, device=self.device)
+        check(self.lib.effq_gram_accum_i8_unw(_ptr(xidx_ndhwc), _ptr(y), C.byref(geom), int(has_bias), _ptr(al),
+                                              int(act_levels), _ptr(lst), _ptr(chunk_cls), _ptr(cls_w), int(ncls),
+                                              0 if lst is None else int(lst.numel()), _ptr(A0), _ptr(B0), acc,
+                                              _ptr(Au), _ptr(Bu), _ptr(ws), ws.numel(), self.stream),
+              "effq_gram_accum_i8_unw")
+        return (A0, B0, Au, Bu) if unweighted else (A0, B0)
+
+    def gram_loss(self, Au: torch.Tensor, Bu: torch.Tensor, syy: torch.Tensor, G: torch.Tensor, b, sqerr=None):
+        """Squared error of conv(Qx, G, b) against the FP target from the unweighted Gram system (effq_gram_loss)."""
+        c2, n = (int(i) for i in Bu.shape)
+        has_b = b is not None
+        if (Au.dtype != torch.float64 or Bu.dtype != torch.float64 or syy.dtype != torch.float64 or
+                tuple(Au.shape) != (n, n) or G.numel() != c2 * (n - int(has_b))):
+            raise _lib.EffqError("gram_loss: operand shapes / dtypes do not match")
+        if sqerr is None:
+            sqerr = torch.zeros(2, dtype=torch.float64, device=self.device)
+        ws = self._workspace("gram_loss", self.lib.effq_gram_loss_ws_bytes(n))
+        check(self.lib.effq_gram_loss(_ptr(Au), _ptr(Bu), _ptr(syy), _ptr(self._f32(G)), _ptr(b), c2, n, int(has_b),
+                                      _ptr(sqerr), _ptr(ws), ws.numel(), self.stream), "effq_gram_loss")
+        return sqerr
 
     def gram_reduce(self, A0: torch.Tensor, B0: torch.Tensor, reducer):
         """Data-parallel SUM of a layer's Gram system as ONE message: upper triangle of A0 + B0 (effq_gram_pack)."""
@@ -438,7 +460,7 @@ class HipOps:
     # -- the whole ADMM loop of a layer in one binding call ---------------------------------------------
     def admm_run(self, A0, B0, W0, b0, geom: Geom, y_ndhwc, *, xq=None, xidx=None, act_alpha=None, act_levels: int = 0,
                  loss_kind: int = 0, rho: float, rho_max: float, eta: float, iters: int, period: int, levels: int,
-                 overlap: bool = True):
+                 overlap: bool = True, loss_gram=None):
         """effq_admm_run: enqueue `iters` ADMM iterations (chain on the current stream, per-iteration loss on the
         loss stream, later inverses on the side stream).  Returns a handle with the rings and `hist` (iters x 2
         device doubles, sums of squared errors); no host synchronisation."""
@@ -448,7 +470,9 @@ class HipOps:
         W0 = self._f32(W0)
         nw = W0.numel()
         y = self._f32(y_ndhwc)
-        _check_shapes(geom, xq if loss_kind == 0 else xidx, W0, b0, y)
+        if loss_gram is not None:
+            loss_kind = 4                         # (Au, Bu, syy): losses from the unweighted Gram system
+        _check_shapes(geom, xq if loss_kind in (0, 4) else xidx, W0, b0, y)
         if tuple(A0.shape) != (n, n) or nw != c2 * (n - int(has_b)):
             raise _lib.EffqError("admm_run: A0/B0/W0 shapes do not match")
         n_inv = self.lib.effq_admm_num_inverses(float(rho), float(rho_max), int(iters), int(period))
@@ -462,7 +486,7 @@ class HipOps:
         r.wstar = torch.empty(nw, dtype=f32, device=dev)
         r.v = torch.empty(nw, dtype=f32, device=dev)
         r.G_ring = torch.empty(iters, nw, dtype=f32, device=dev)
-        r.Gq_ring = torch.empty(iters, nw, dtype=torch.int8, device=dev) if loss_kind != 0 else None
+        r.Gq_ring = torch.empty(iters, nw, dtype=torch.int8, device=dev) if loss_kind in (1, 2) else None
         r.b_ring = torch.empty(iters, c2, dtype=f32, device=dev) if has_b else None
         r.state_ring = torch.zeros(iters, 5, dtype=torch.float64, device=dev)
         r.hist = torch.zeros(iters, 2, dtype=torch.float64, device=dev)
@@ -477,14 +501,16 @@ class HipOps:
         inv_side = self._workspace("inv_side", self.lib.effq_spd_inverse_ws_bytes(n)) if n_inv > 1 else None
         fpw = (self._workspace("fp_bucket", self.lib.effq_fp_bucket_ws_bytes(nw))
                if nw <= self.lib.effq_fp_bucket_max() and BUCKET_FIXED_POINT else None)
-        if loss_kind == 1:
+        if loss_kind == 4:
+            cws = self._workspace("gram_loss", self.lib.effq_gram_loss_ws_bytes(n))
+        elif loss_kind == 1:
             cws = self._workspace("conv_i8", self.lib.effq_conv_i8_ws_bytes(C.byref(geom)))
         elif loss_kind == 2:
             cws = self._workspace("conv_i8s", self.lib.effq_conv_i8s_ws_bytes(C.byref(geom), int(act_levels),
                                                                              int(levels)))
         else:
             cws = self._workspace("conv", self.lib.effq_conv_ws_bytes(C.byref(geom)))
-        al = self._f32(act_alpha.reshape(1)) if (act_alpha is not None and loss_kind != 0) else None
+        al = self._f32(act_alpha.reshape(1)) if (act_alpha is not None and loss_kind in (1, 2)) else None
         a = _lib.AdmmRunArgs()
         p = lambda t: None if t is None else t.data_ptr()
         a.A0, a.B0, a.W0, a.b0 = p(self._f32(A0)), p(self._f32(B0)), p(W0), p(b0)
@@ -494,7 +520,13 @@ class HipOps:
         a.geom = geom
         a.loss_kind, a.act_levels = int(loss_kind), int(act_levels)
         a.xq = p(self._f32(xq)) if loss_kind == 0 else None
-        a.xidx = p(xidx) if loss_kind != 0 else None
+        a.xidx = p(xidx) if loss_kind in (1, 2) else None
+        if loss_kind == 4:
+            Au, Bu, syy = loss_gram
+            if (Au.dtype != torch.float64 or Bu.dtype != torch.float64 or syy.dtype != torch.float64 or
+                    tuple(Au.shape) != (n, n) or tuple(Bu.shape) != (c2, n) or syy.numel() != 1):
+                raise _lib.EffqError("admm_run: loss_gram wants fp64 (Au [n,n], Bu [c2,n], syy [1])")
+            a.loss_Au, a.loss_Bu, a.loss_syy = p(Au), p(Bu), p(syy)
         a.y_fp, a.act_alpha_dev = p(y), p(al)
         a.dual, a.wstar, a.v = p(r.dual), p(r.wstar), p(r.v)
         a.G_ring, a.Gq_ring, a.b_ring = p(r.G_ring), p(r.Gq_ring), p(r.b_ring)
@@ -509,7 +541,7 @@ class HipOps:
         a.stream_main = main.cuda_stream
         a.stream_loss = loss_s.cuda_stream if loss_s is not None else None
         a.stream_side = side_s.cuda_stream if inv_side is not None else None
-        r.keep = (A0, B0, W0, b0, y, xq, xidx, al)       # the call only enqueues: keep every operand alive
+        r.keep = (A0, B0, W0, b0, y, xq, xidx, al, loss_gram)       # the call only enqueues: keep every operand alive
         check(self.lib.effq_admm_run(C.byref(a)), "effq_admm_run")
         return r
 

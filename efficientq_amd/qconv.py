@@ -27,6 +27,9 @@ import os as _os
 EXACT_INT_DEFAULT = _os.environ.get("EFFQ_EXACT_INT", "1") != "0"
 # evaluate the loss of iteration i on a second stream while the chain computes iteration i+1
 OVERLAP_LOSS_DEFAULT = _os.environ.get("EFFQ_OVERLAP_LOSS", "1") != "0"
+# per-iteration losses from the unweighted Gram system (effq_gram_loss) for layers with n = k^3 c1 + 1 up to this size
+GRAM_LOSS_DEFAULT = _os.environ.get("EFFQ_GRAM_LOSS", "1") != "0"
+GRAM_LOSS_MAX_N = int(_os.environ.get("EFFQ_GRAM_LOSS_MAX_N", "1729"))
 
 
 def get_ops(device):
@@ -290,7 +293,9 @@ class EfficientQConvHIP(PTQConv):
         nw = W0.numel() // c2
 
         # rho_scale = max(numel(y)*std(y) / (numel(W)*std(W)), 1)          (EfficientQConv.py:43-49)
-        my = red(ops.moments(yn))
+        my = ops.moments(yn)
+        syy_local = my[1:2].clone()           # sum y^2 over THIS rank's voxels (the loss from the Gram system adds it)
+        my = red(my)
         mw = ops.moments(W0)
         y_dim = my[2].item()
         rho_scale = max(y_dim * self._std(my) / (W0.numel() * self._std(mw)), 1.0)
@@ -336,7 +341,18 @@ class EfficientQConvHIP(PTQConv):
         rho_m = self.lwq_rho_max * rho_scale
         eta = self.lwq_eta * rho_scale
 
-        if use_gi8:                                                        # (:87-91, solver.py:282-314)
+        # Losses of the 200 iterates from the unweighted Gram system of the same integer pass (effq_gram_loss) instead of
+        # 200 passes over the voxels, where the voxel count is far above n = k^3 c1 + 1 (the conv is cheaper on the small
+        # volumes of the wide layers)
+        n_sys = nw + int(has_b)
+        loss_gram = None
+        use_gl = bool(use_gi8 and GRAM_LOSS_DEFAULT and hasattr(ops, "gram_loss") and n_sys <= GRAM_LOSS_MAX_N and
+                      yn.numel() // c2 >= 8 * n_sys)
+        if use_gi8 and use_gl:
+            A0, B0, Au, Bu = ops.gram_i8(xidx, att_cls, yn, geom, has_b, self.alpha_act.data, self.qlvl_act,
+                                         unweighted=True)
+            loss_gram = (Au, Bu, syy_local)
+        elif use_gi8:                                                      # (:87-91, solver.py:282-314)
             A0, B0 = ops.gram_i8(xidx, att_cls, yn, geom, has_b, self.alpha_act.data, self.qlvl_act)
         else:
             A0, B0 = ops.gram(xq, att, yn, geom, has_b)
@@ -356,10 +372,11 @@ class EfficientQConvHIP(PTQConv):
         import time as _time
         t_loop0 = _time.perf_counter()
         loss_kind = 1 if use_i8 else (2 if use_i8s else 0)
+        kw = dict(loss_gram=loss_gram) if loss_gram is not None else {}
         run = ops.admm_run(A0, B0, W0, b0, geom, yn, xq=xq, xidx=xidx, act_alpha=self.alpha_act.data,
                            act_levels=self.qlvl_act, loss_kind=loss_kind, rho=rho, rho_max=rho_m, eta=eta,
                            iters=self.lwq_iter, period=RHO_PERIOD, levels=self.qlvl_w,
-                           overlap=self.lwq_overlap_loss)
+                           overlap=self.lwq_overlap_loss, **kw)
         t_enq = _time.perf_counter() - t_loop0     # host time to enqueue the 200 iterations (diagnostic)
         red(run.hist)
         best_G, best_b, best = ops.admm_select_best(run)
@@ -392,7 +409,8 @@ class EfficientQConvHIP(PTQConv):
         self.last_trace = dict(rho_scale=rho_scale, best_iter=int(best_h[1]), best_mse=best_h[0] / numel,
                                final_mse=fin_h[0] / numel, layer_loss=lossf, act_iters=act_iters,
                                w_iters=w_iters, alpha_w=a_w, loss_history=[h / numel for h in hist],
-                               exact_int=int_conv, exact_gram=use_gi8, host_enqueue_s=t_enq, admm_loop_s=t_loop)
+                               exact_int=int_conv or loss_gram is not None, exact_gram=use_gi8,
+                               gram_loss=loss_gram is not None, host_enqueue_s=t_enq, admm_loop_s=t_loop)
 
     def compute_quant_error(self, output_fp, Qw, Qact):
         """EfficientQConv.py:168-172."""

@@ -158,6 +158,23 @@ int effq_gram_accum_i8(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const ef
                        const float* act_alpha_dev, int act_levels, const int32_t* vox_list,
                        const int32_t* chunk_cls, const float* cls_w_dev, int ncls, long long n_list,
                        float* A0, float* B0, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The same pass with the UNWEIGHTED system as a by-product, in fp64: Au [n][n] = sum_v xhat xhat^T (reference row order,
+ * ones row included, no factor 2), Bu [c2][n] = sum_v y xhat^T - the integer class slabs summed without the attention
+ * weights.  Au / Bu may both be NULL (= effq_gram_accum_i8). */
+int effq_gram_accum_i8_unw(const uint8_t* xidx_ndhwc, const float* y_ndhwc, const effq_geom* g, int has_bias,
+                           const float* act_alpha_dev, int act_levels, const int32_t* vox_list, const int32_t* chunk_cls,
+                           const float* cls_w_dev, int ncls, long long n_list, float* A0, float* B0, int accumulate,
+                           double* Au, double* Bu, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- the loss of one iterate from the unweighted Gram system (EfficientQConv.py:118-122 without the pass over the voxels)
+ * sum_v,c (conv(Qx, G, b)_v,c - y_v,c)^2 = sum_c g_c^T Au g_c - 2 sum_c g_c . Bu_c + syy with g_c = [G[c,:], b_c], in fp64:
+ * sqerr_out[0] = sqerr_out[1] = that sum (the unweighted squared error, as the conv entry points report it).  c2 n^2
+ * multiply-adds on an n x n matrix instead of a pass over all voxels: for layers whose voxel count is far above n.
+ * ws: effq_gram_loss_ws_bytes(n), zero-filled once by the caller. */
+size_t effq_gram_loss_ws_bytes(int n);
+int effq_gram_loss(const double* Au, const double* Bu, const double* syy_dev, const float* G, const float* b, int c2, int n,
+                   int has_bias, double* sqerr_out, void* ws, size_t ws_bytes, void* stream);
+
 
 /* The voxel list of an attention mask, by three small kernels (distinct weights + counts, segment layout, scatter): the
  * class weights are the few integers quirk Q1 leaves (ptqer.py:161-165).  vox_list: V + 2048 int32, chunk_cls: V/128 + 16
@@ -309,7 +326,7 @@ int effq_admm_chain_step(const effq_chain_args* a, void* stream);
  * and dual is divided by the same factor (EfficientQConv.py:129-137).  One inverse per distinct rho that serves more
  * than one iteration: ainv_pool holds n_ainv >= effq_admm_num_inverses(...) matrices of n*effq_ainv_ld(n) floats.
  * loss_kind: 0 = conv3d_quant_calib_step on xq (fp32), 1 = conv3d_calib_step_i8, 2 = conv3d_calib_step_i8s (both on
- * xidx, act_alpha_dev, act_levels).  Workspaces as the respective entry points document them (conv_ws zero-filled
+ * xidx, act_alpha_dev, act_levels), 4 = effq_gram_loss (no pass over the voxels; loss_Au / loss_Bu / loss_syy below).  Workspaces as the respective entry points document them (conv_ws zero-filled
  * once; red_ws = the reduction workspace; fp_ws = effq_fp_bucket_ws_bytes(nw), may be NULL -> cooperative fixed point;
  * inv_ws / inv_ws_side = effq_spd_inverse_ws_bytes(n) each, the second only with stream_side).
  * *err_flag (device int32, zeroed by the caller) is set when a weight fixed point hits its cap (layer_helper.py:62-64). */
@@ -332,6 +349,10 @@ typedef struct effq_admm_run_args {
   void* inv_ws_side; size_t inv_ws_side_bytes;
   void* conv_ws; size_t conv_ws_bytes;
   void* stream_main; void* stream_loss; void* stream_side;
+  /* loss_kind 4: the loss of an iterate from the layer's unweighted Gram system (effq_gram_loss): Au [n][n], Bu [c2][n]
+   * (effq_gram_accum_i8_unw), syy = one device double, sum y^2 over this rank's voxels; conv_ws = effq_gram_loss_ws_bytes(n)
+   * zero-filled once.  NULL for the other kinds. */
+  const double* loss_Au; const double* loss_Bu; const double* loss_syy;
 } effq_admm_run_args;
 int effq_admm_num_inverses(double rho, double rho_max, int iters, int rho_period);
 int effq_admm_run(const effq_admm_run_args* a);

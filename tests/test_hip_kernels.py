@@ -436,6 +436,61 @@ def test_exact_int_conv_step_equals_fp32_path(ops, c1, c2, La, Lw, sp):
     assert sq8b.cpu().tolist() == s8
 
 
+@pytest.mark.parametrize("c1,c2,k,pad,sp,La,Lw,att_kind,with_bias", [
+    (32, 32, 3, 1, (8, 8, 16), 4, 4, "none", True), (32, 32, 3, 1, (9, 7, 11), 4, 4, "classes0", True),
+    (64, 64, 3, 1, (8, 8, 8), 16, 16, "classes", False), (32, 64, 1, 0, (6, 5, 7), 4, 4, "classes", True),
+    (16, 8, 3, 1, (5, 6, 9), 4, 16, "none", True)])
+def test_loss_from_the_unweighted_gram_system_equals_the_conv_loss(ops, c1, c2, k, pad, sp, La, Lw, att_kind, with_bias):
+    """effq_gram_loss: sum (conv(Qx, G, b) - y)^2 = sum_c g_c^T Au g_c - 2 g_c . Bu_c + sum y^2 with the UNWEIGHTED fp64
+    system that effq_gram_accum_i8_unw produces beside the attention-weighted A0 / B0.  Against the fp64 evaluation of the
+    same integer model: <= 1e-9 (the attention weights - zeros included - must not enter); against the conv entry point
+    (fp32 epilogue): <= 2e-6; A0 / B0 themselves are unchanged by asking for the by-product."""
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(c1 + 3 * c2 + La + k)
+    N = 2
+    x = torch.relu(torch.randn(N, *sp, c1, generator=gen))
+    geom = make_geom((N, c1, *sp), c2, k, 1, pad)
+    od, oh, ow = geom.out_dims()
+    a_act, _, st_a = ops.fit_scale(dev(x), La, 0.0, 1.0)
+    xq, _, xidx = ops.quant_dequant_f64path(dev(x), st_a, La, 0.0, 1.0, want_idx=True)
+    alpha_act = torch.tensor(a_act, dtype=torch.float32, device="cuda:0")
+    y = dev(torch.randn(N, od, oh, ow, c2, generator=gen))
+    att = None
+    if att_kind != "none":
+        lo = 0 if att_kind == "classes0" else 1
+        att = dev(torch.randint(lo, 4, (N, od, oh, ow), generator=gen).float())
+    cls = ops.att_classes(att)
+    A0, B0, Au, Bu = ops.gram_i8(xidx, cls, y, geom, with_bias, alpha_act, La, unweighted=True)
+    A0b, B0b = ops.gram_i8(xidx, cls, y, geom, with_bias, alpha_act, La)
+    assert torch.equal(A0, A0b) and torch.equal(B0, B0b)
+    # the unweighted system against fp64 on the host: the integer model xhat = s * level id, s = alpha_act / (La - 1)
+    sx = float(np.float32(a_act)) / (La - 1)
+    X = O.patch_matrix(xidx.cpu().permute(0, 4, 1, 2, 3).float().numpy(), (k, k, k), 1, pad,
+                       ones_row=with_bias).astype(np.float64)
+    X[:c1 * k ** 3] *= sx
+    Y = y.cpu().double().reshape(-1, c2).numpy().T
+    assert np.abs(Au.cpu().numpy() - X @ X.T).max() <= 1e-12 * np.abs(X @ X.T).max()
+    assert np.abs(Bu.cpu().numpy() - Y @ X.T).max() <= 2e-8 * np.abs(Y @ X.T).max()     # y rides in 32-bit fixed point
+    # an iterate: projected weights of a perturbed solution
+    wst = dev(torch.randn(c2, c1, k, k, k, generator=gen) * 0.05)
+    dual, v, G = torch.zeros_like(wst), torch.empty_like(wst), torch.empty_like(wst)
+    st_w = ops.new_fp_state()
+    ops.weight_fixed_point(wst, dual, v, Lw, st_w)
+    Gq = torch.empty(wst.shape, dtype=torch.int8, device="cuda:0")
+    ops.admm_project_dual(v, wst, st_w, Lw, G, dual, 1.0, Gq)
+    b = dev(torch.randn(c2, generator=gen) * 0.1) if with_bias else None
+    syy = (y.double() ** 2).sum().reshape(1)
+    got = ops.gram_loss(Au, Bu, syy, G, b).cpu().tolist()
+    out = torch.nn.functional.conv3d(xidx.cpu().permute(0, 4, 1, 2, 3).double() * sx, G.cpu().double(),
+                                     None if b is None else b.cpu().double(), 1, pad)
+    ref = ((out - y.cpu().permute(0, 4, 1, 2, 3).double()) ** 2).sum().item()
+    assert abs(got[0] - ref) <= 2e-8 * ref, (got, ref)
+    assert got[1] == got[0]
+    _, sq32 = ops.conv_step(xq, G, b, geom, y, None)
+    assert abs(sq32.cpu().tolist()[0] - got[0]) <= 2e-6 * ref
+    assert ops.gram_loss(Au, Bu, syy, G, b).cpu().tolist() == got          # deterministic
+
+
 @pytest.mark.parametrize("sp,La,Lw,with_bias", [((16, 8, 8), 4, 4, True), ((5, 6, 9), 4, 4, True), ((17, 4, 8), 16, 16, False),
                                                   ((33, 7, 10), 4, 4, True)])
 def test_paired_exact_int_conv_equals_two_single_passes(ops, sp, La, Lw, with_bias):
