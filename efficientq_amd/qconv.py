@@ -242,8 +242,10 @@ class PTQConv(nn.Conv3d):
         if self._fp:
             return self._conv(x, False)
         if self._quantizing:
+            self._ptq_out = None
             self.ptq(x)
-            return self._conv(x, self.q_act)
+            out, self._ptq_out = getattr(self, "_ptq_out", None), None
+            return from_ndhwc(out) if out is not None else self._conv(x, self.q_act)
         if self._quantized:
             if torch.is_grad_enabled() and (self.alpha_act.requires_grad or x.requires_grad):
                 return _QuantConvFn.apply(x, self.alpha_act, self)      # tune_activation_range (row f3)
@@ -399,7 +401,14 @@ class EfficientQConvHIP(PTQConv):
             self.bias.data = best_b
         self.alpha_w.data = torch.tensor(a_w, dtype=x.dtype, device=dev)   # LAST iterate's scale (quirk Q6)
 
-        _, fin = ops.conv_step(xq, best_G, best_b, geom, yn, att)          # (:161-166)
+        # (:161-166) the final loss - and, from the same pass, the layer's quantised output, which forward() hands to the
+        # next layer right after this call (PTQConv.py:160-163 runs the same conv a second time): the fp32 activation
+        # quant-dequant is fused into the tile load, exactly as in the quantised forward
+        fuse = self.q_act and not self._act_inited
+        out, fin = ops.conv_step(xn if fuse else xq, best_G, best_b, geom, yn, att,
+                                 act_alpha=self.alpha_act.data if fuse else None,
+                                 act_levels=self.qlvl_act if fuse else 0, want_out=True)
+        self._ptq_out = out if (fuse or not self.q_act) else None
         red(fin)
         fin_h = fin.tolist()
         numel = y_dim * 1.0
