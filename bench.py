@@ -208,9 +208,13 @@ class OpTimer:
                 f"peak [{r['stream']}]  {r['kernel'][:88]}")
         if not rows:
             return None, [], busy
-        # `roofline` = the largest SINGLE-KERNEL op (its duration can be checked against the rocprofv3 kernel summary);
-        # multi-kernel ops (prox solve = 3 kernels, inverse = a few hundred) are listed with the others as composite
-        first = next((i for i, r in enumerate(rows) if not r["composite"]), 0)
+        # `roofline` = the largest SINGLE-KERNEL op of the MAIN stream - the critical path (its duration can be checked
+        # against the rocprofv3 kernel summary).  Ops of the loss and side streams run beside it and their in-situ
+        # durations are mostly time spent waiting for CUs (the 256-channel loss conv takes 0.05 ms alone and 0.3 ms
+        # between the workgroups of the prox GEMM); multi-kernel ops (inverse = a few hundred kernels, the multi-launch
+        # fixed points) are listed with the others as composite.
+        first = next((i for i, r in enumerate(rows) if not r["composite"] and r["stream"] == "main"),
+                     next((i for i, r in enumerate(rows) if not r["composite"]), 0))
         rows.insert(0, rows.pop(first))
         return rows[0], rows[1:9], busy
 
