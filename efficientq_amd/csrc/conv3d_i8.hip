@@ -70,9 +70,12 @@ __global__ __launch_bounds__(256) void k_pack_weight_i8g(const int8_t* __restric
   extern __shared__ __attribute__((aligned(16))) int8_t rows[];          // [4][C1 * T]
   const int rowb = C1 * T;
   const int j0 = blockIdx.x * 4;
-  for (int e = threadIdx.x; e < 4 * rowb; e += 256) {
-    const int jj = e / rowb, o = e - jj * rowb;
-    rows[e] = (j0 + jj < C2) ? Gq[(size_t)(j0 + jj) * rowb + o] : (int8_t)0;
+  const int rowv = rowb / 16;                      // C1 % 16 == 0: rows are whole 16-byte vectors
+  for (int e = threadIdx.x; e < 4 * rowv; e += 256) {
+    const int jj = e / rowv, o = e - jj * rowv;
+    v4i val = {0, 0, 0, 0};
+    if (j0 + jj < C2) val = *reinterpret_cast<const v4i*>(Gq + (size_t)(j0 + jj) * rowb + (size_t)o * 16);
+    *reinterpret_cast<v4i*>(rows + (size_t)jj * rowb + (size_t)o * 16) = val;
   }
   __syncthreads();
   const int ncell = T * (C1 / 16);                                       // cells per output channel
