@@ -213,6 +213,44 @@ def test_exact_int_and_fp32_loss_paths_agree_on_a_layer():
     assert abs(res[True][1] - res[False][1]) <= 5e-3 * res[False][1]
 
 
+def test_losses_from_the_gram_system_equal_the_conv_losses_on_a_layer(monkeypatch):
+    """The loss only picks the best iterate: with the 200 losses taken from the unweighted Gram system (effq_gram_loss)
+    or from 200 exact-integer conv passes the ADMM chain is the same, so ALL 200 losses must agree to the fp32 rounding
+    of the conv epilogue (2e-6) and the winners must be equivalent (layer_loss and output within north_star's 1e-3).  With an
+    attention mask (the loop's loss is unweighted, the Gram system is not: quirk Q5)."""
+    import efficientq_amd.qconv as Q
+    res = {}
+    for gram_loss in (True, False):
+        monkeypatch.setattr(Q, "GRAM_LOSS_DEFAULT", gram_loss)
+        gen = torch.Generator().manual_seed(7)
+        c, S, N = 32, 20, 2
+        conv = Q.EfficientQConvHIP(c, c, 3, 1, 1, 1, 1, True, q_weight=True, qlvl=4, q_act=True, qlvl_act=4, lwq_trace=True)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (c * 27)) ** 0.5)
+            conv.bias.copy_(torch.randn(c, generator=gen) * 0.1)
+        x_fp = torch.relu(torch.randn(N, c, S, S, S, generator=gen))
+        y = torch.nn.functional.conv3d(x_fp, conv.weight.data, conv.bias.data, 1, 1)
+        x = torch.relu(x_fp + 0.05 * torch.randn(x_fp.shape, generator=gen))
+        conv.output_fp, conv.name, conv.layer_loss = y, "l", []
+        conv.mask_pyramid = [torch.randint(0, 4, (N, S, S, S), generator=gen).float()]
+        _to_dev(conv)
+        conv.set_quantizing()
+        with torch.no_grad():
+            out = conv(x.to(DEV))
+        tr = conv.last_trace
+        assert tr["gram_loss"] == gram_loss and tr["exact_int"] and tr["exact_gram"]
+        res[gram_loss] = (np.array(tr["loss_history"]), tr["best_iter"], conv.weight.data.cpu().clone(), out.cpu().clone(),
+                          float(conv.layer_loss[0].split(":")[1]))
+    hg, hc = res[True][0], res[False][0]
+    assert hg.shape == (200,) and np.all(np.abs(hg - hc) <= 2e-6 * hc), np.abs(hg / hc - 1).max()
+    # the winner: on the plateau several iterates lie within the conv path's own rounding of each other (here 115 and 117),
+    # so the two paths may pick different ones among them - never one that the other path sees as worse by more than that
+    bg, bc = res[True][1], res[False][1]
+    assert abs(hc[bg] - hc[bc]) <= 4e-6 * hc[bc] and abs(hg[bg] - hg[bc]) <= 4e-6 * hg[bc], (bg, bc)
+    assert abs(res[True][4] - res[False][4]) <= 1e-3 * res[False][4]
+    assert _rel_mse(res[True][3], res[False][3]) <= 1e-3
+
+
 def test_data_parallel_two_ranks_on_one_gpu_matches_single_rank(tmp_path):
     """The sharded HIP path (volumes split over 2 ranks, Gram / statistics / losses all-reduced) against the
     unsharded one.  Both ranks share cuda:0; the collective is gloo with host staging (RCCL refuses two ranks
