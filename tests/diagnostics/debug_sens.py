@@ -1,6 +1,6 @@
 """Diagnostic (GPU): where does the per-iteration loss gap vs the oracle come from?"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, torch.nn.functional as F
 from oracle import effq_oracle as O
 from efficientq_amd.hip_ops import get_ops, make_geom, to_ndhwc

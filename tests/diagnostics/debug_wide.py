@@ -1,12 +1,12 @@
 """Diagnostic (GPU): stage-by-stage error of the first ADMM iteration of the wide golden layers (g5b) vs fp64."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, torch.nn.functional as F
 from oracle import effq_oracle as O
 from efficientq_amd.hip_ops import get_ops, make_geom, to_ndhwc
 T = lambda a: torch.from_numpy(np.array(a)).clone()
 tag = sys.argv[1] if len(sys.argv) > 1 else "c64"
-g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/g5b_wide_layers.npz"))
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests/golden/g5b_wide_layers.npz"))
 x, y, w, b = T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), T(g[f"{tag}_w_in"]), T(g[f"{tag}_b_in"])
 att = T(g[f"{tag}_mask_full"]).float()
 c = w.shape[0]

@@ -86,7 +86,7 @@ def test_wide_layer_calibration_within_reference_self_spread(gold, tag):
         # The first iterations: north_star's bar / 10, or 5x the largest distance the two reference runs have shown
         # between themselves up to that iteration.  One weight index that flips at a rounding tie moves the loss of an
         # iteration by 2e-4..1e-3 at 64 channels (measured by perturbing w* by 1e-5 relative, the accuracy of the
-        # reference's own fp32 LU solve at cond(A) = 1.6e4: scripts/debug_wide.py); the reference's runs with 1 and 8
+        # reference's own fp32 LU solve at cond(A) = 1.6e4: tests/diagnostics/debug_wide.py); the reference's runs with 1 and 8
         # threads are 7e-4 apart at iteration 0 already and 1.7 % by iteration 4, and both are 2e-4 away from exact
         # fp64 arithmetic at iteration 1, where they happen to agree with each other to 2e-7.
         self5 = np.abs(g[f"{tag}_t1_loss_hist"][:5] - g[f"{tag}_t8_loss_hist"][:5]) / g[f"{tag}_t8_loss_hist"][:5]
