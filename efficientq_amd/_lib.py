@@ -129,6 +129,7 @@ SIGNATURES = {
     "effq_gram_i8_ws_bytes": (_SZ, [_GP, _I]),
     "effq_gram_accum_i8": (_I, [_P, _P, _GP, _I, _P, _I, _P, _P, _P, _I, _LL, _P, _P, _I, _P, _SZ, _P]),
     "effq_gram_accum_i8_unw": (_I, [_P, _P, _GP, _I, _P, _I, _P, _P, _P, _I, _LL, _P, _P, _I, _P, _P, _P, _SZ, _P]),
+    "effq_upsample_trilinear": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "effq_gram_loss_ws_bytes": (_SZ, [_I]),
     "effq_gram_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "effq_packed_bytes": (_SZ, [_SZ, _I]),

@@ -349,6 +349,16 @@ class HipOps:
               "effq_gram_accum_i8_unw")
         return (A0, B0, Au, Bu) if unweighted else (A0, B0)
 
+    def upsample_trilinear(self, x_ndhwc: torch.Tensor, scale) -> torch.Tensor:
+        """nn.Upsample(scale_factor=scale, mode='trilinear') on an NDHWC tensor (effq_upsample_trilinear)."""
+        x = self._f32(x_ndhwc)
+        N, D, H, W, Cc = (int(i) for i in x.shape)
+        sd, sh, sw = (int(i) for i in scale)
+        out = torch.empty(N, D * sd, H * sh, W * sw, Cc, dtype=torch.float32, device=self.device)
+        check(self.lib.effq_upsample_trilinear(_ptr(x), N, D, H, W, Cc, sd, sh, sw, _ptr(out), self.stream),
+              "effq_upsample_trilinear")
+        return out
+
     def gram_loss(self, Au: torch.Tensor, Bu: torch.Tensor, syy: torch.Tensor, G: torch.Tensor, b, sqerr=None):
         """Squared error of conv(Qx, G, b) against the FP target from the unweighted Gram system (effq_gram_loss)."""
         c2, n = (int(i) for i in Bu.shape)

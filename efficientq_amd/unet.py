@@ -2,7 +2,8 @@
 reference's checkpoints load unchanged (identical ``state_dict`` keys) and layers are visited
 in the same order.  Reference: src/models/model_blk.py:49-207, factoryQ.py:66-81,182-237,
 factory_blk.py:18-166.  Only the quantised convolutions compute through the HIP library; ReLU /
-pooling / trilinear up-sampling / skip additions are torch device ops (plumbing between layers).
+pooling / skip additions are torch device ops (plumbing between layers); the trilinear up-sampling has a channels-last
+library kernel (TrilinearUp).
 
 Parity-relevant behaviours kept on purpose:
   * the first ReLU of every conv unit is in-place, so a residual block adds relu(x), not x
@@ -21,6 +22,30 @@ import torch.nn as nn
 class PassModule(nn.Module):
     def forward(self, x):
         return x
+
+
+class TrilinearUp(nn.Upsample):
+    """nn.Upsample(scale_factor, mode='trilinear') of the decoder (factory_blk.py:70-93).  On a HIP device, without
+    autograd, for per-axis factors 1 / 2 it runs the library's channels-last kernel (effq_upsample_trilinear: the
+    framework's kernel indexes NCDHW and took 18 ms per calibration on channels-last tensors); otherwise the module is
+    exactly nn.Upsample.  No parameters: checkpoints are unaffected."""
+
+    def forward(self, x):
+        sf = self.scale_factor
+        sc = tuple(int(v) for v in sf) if isinstance(sf, (tuple, list)) else (int(sf),) * 3
+        plain = (x.is_cuda and x.dim() == 5 and x.dtype == torch.float32 and len(sc) == 3 and
+                 all(v in (1, 2) for v in sc) and
+                 tuple(float(v) for v in (sf if isinstance(sf, (tuple, list)) else (sf,) * 3)) == tuple(float(v) for v in sc)
+                 and not (torch.is_grad_enabled() and x.requires_grad) and FAST_UPSAMPLE)
+        if not plain:
+            return super().forward(x)
+        from .hip_ops import get_ops
+        from .qconv import from_ndhwc, to_ndhwc
+        return from_ndhwc(get_ops(x.device).upsample_trilinear(to_ndhwc(x), sc))
+
+
+import os as _os
+FAST_UPSAMPLE = _os.environ.get("EFFQ_FAST_UPSAMPLE", "1") != "0"
 
 
 class ConvUnit(nn.Module):
@@ -78,7 +103,7 @@ class Fuser(nn.Module):
         self.upsampler = nn.Sequential()
         if cin != cskip:
             self.upsampler.add_module('block', ConvUnit(kind, cin, cskip, 1, 1, 0, 1, Conv, bn, False, 0))
-        self.upsampler.add_module('trilinear', nn.Upsample(scale_factor=scale, mode='trilinear'))
+        self.upsampler.add_module('trilinear', TrilinearUp(scale_factor=scale, mode='trilinear'))
 
     def forward(self, x, skip):
         return self.upsampler(x) + skip
@@ -156,12 +181,12 @@ class UResQ(nn.Module):
                         head.add_module('classifier', nn.Conv3d(w, num_classes, 1, 1, 0))
                         up = _scaled(init_stride, 2 ** len(width_config[i + 1:]))
                         if up not in (1, (1, 1), (1, 1, 1)):
-                            head.add_module('extra_up', nn.Upsample(scale_factor=up, mode='trilinear'))
+                            head.add_module('extra_up', TrilinearUp(scale_factor=up, mode='trilinear'))
                     self.classifiers.add_module(f'AuxClassifier{i + 1}', head)
         self.final_cls = nn.Sequential()
         self.final_cls.add_module('cls', ConvLast(width_config[-1], num_classes, 1, 1, 0))
         if init_stride not in (1, (1, 1), (1, 1, 1)):
-            self.final_cls.add_module('extra_up', nn.Upsample(scale_factor=init_stride, mode='trilinear'))
+            self.final_cls.add_module('extra_up', TrilinearUp(scale_factor=init_stride, mode='trilinear'))
 
     def load_state_dict(self, state_dict, strict=True, init=True):
         r = super().load_state_dict(state_dict, strict)

@@ -384,6 +384,11 @@ int effq_prof_enable(int every);
 int effq_prof_count(void);
 int effq_prof_read(int i, effq_prof_record* out);
 
+/* ---- glue between the quantised convs (row a11): x2 trilinear up-sampling of the decoder (factory_blk.py:70-93,
+ * nn.Upsample(scale_factor, mode='trilinear'), align_corners = False) on NDHWC tensors; per-axis scale 1 or 2. */
+int effq_upsample_trilinear(const float* x_ndhwc, int N, int D, int H, int W, int C, int sd, int sh, int sw,
+                            float* y_ndhwc, void* stream);
+
 /* ---- f2: bit-packed storage of level ids ---------------------------------------------------
  * The reference stores one uint8 per weight (store_int_weight, PTQConv.py:125-152); these pack the level ids
  * at 1/2/4/8 bits each (little-endian bit stream: element i in bits [i*bits, (i+1)*bits)) and back. */

@@ -837,3 +837,17 @@ def test_chain_step_equals_the_separate_entry_points(ops, c2, c1k, L, shift):
         assert i0 == i1 and d0 == d1 and abs(a0 - a1) <= 1e-13 * abs(a0)
     else:
         assert outs[0][-1] == outs[1][-1]
+
+
+@pytest.mark.parametrize("C,sp,scale", [(32, (4, 6, 5), (2, 2, 2)), (3, (5, 4, 7), (2, 2, 2)), (64, (3, 3, 4), (2, 2, 1)),
+                                         (8, (1, 2, 3), (1, 2, 2))])
+def test_trilinear_upsampling_matches_the_framework(ops, C, sp, scale):
+    """effq_upsample_trilinear (channels-last) against nn.Upsample(scale_factor, mode='trilinear') of the reference's
+    decoder: same source-index and interpolation arithmetic in fp32 (<= 1e-6 of the value range; the framework's build
+    may contract to FMAs)."""
+    gen = torch.Generator().manual_seed(C)
+    x = torch.randn(2, C, *sp, generator=gen)
+    want = torch.nn.functional.interpolate(x, scale_factor=tuple(float(s) for s in scale), mode="trilinear")
+    got = ops.upsample_trilinear(dev(_ndhwc(x)), scale).permute(0, 4, 1, 2, 3).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 1e-6 * want.abs().max()
