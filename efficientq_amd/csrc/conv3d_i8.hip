@@ -252,6 +252,150 @@ __global__ __launch_bounds__(256, (CG <= 4) ? 2 : 1) void k_conv3d_i8g(ConvI8Par
                      gridDim.x * gridDim.y);
 }
 
+// 512 input channels: the 6 x 6 x 10 halo tile would need 190 KB of LDS, so the tile is 2 x 4 x 8 output voxels (halo
+// 4 x 6 x 10 = 127 KB) and the four waves are 2 d-planes x 2 halves of 64 output channels (blockIdx.y counts groups of
+// 64).  B operands stream through the same 8-deep register ring, one ring load per MFMA step (tap, group).
+constexpr int G2_TD = 2, G2_HD = G2_TD + 2, G2_NH = G2_HD * I_HH * I_HW;    // 240 halo voxels
+constexpr int G2_TS = 68;                                                    // transpose row stride (floats): 64 channels + pad
+template <int CG>
+__global__ __launch_bounds__(256, 1) void k_conv3d_i8g2(ConvI8Params p) {
+  static_assert(CG % 8 == 0, "ring blocks of 8 steps must not straddle taps");
+  constexpr int VS = 32 * CG + 16;
+  constexpr int PADB = halo_row_pad(CG), HALOB = G2_NH * VS + G2_HD * I_HH * PADB;
+  constexpr int NHL = (G2_NH * 2 * CG + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) int8_t dyn_lds[];
+  int8_t* halo = dyn_lds;
+  float* tb = reinterpret_cast<float*>(dyn_lds + ((HALOB + 15) / 16) * 16);   // 64 * G2_TS floats
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int plane = wid & 1, chalf = wid >> 1;
+  const int ch0 = blockIdx.y * 64, chw = ch0 + 32 * chalf;
+  const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per;
+  const int t_end = (t_begin + per < p.ntiles) ? t_begin + per : p.ntiles;
+  const float scale = (float)((double)(*p.act_alpha) * (double)(float)p.wstate->alpha * p.inv_levels);
+  const float bv = (p.bias != nullptr) ? p.bias[chw + li] : 0.0f;
+  const v4i* wbase = reinterpret_cast<const v4i*>(p.wq) + (size_t)lh * p.c2p + chw + li;
+  const size_t wstep = (size_t)2 * p.c2p;
+
+  struct Tile {
+    int n, od0, oh0, ow0;
+  };
+  auto decode = [&](int tile) {
+    Tile r;
+    int t = tile;
+    r.ow0 = (t % p.tiles_w) * ITW;
+    t /= p.tiles_w;
+    r.oh0 = (t % p.tiles_h) * ITH;
+    t /= p.tiles_h;
+    r.od0 = (t % p.tiles_d) * G2_TD;
+    r.n = t / p.tiles_d;
+    return r;
+  };
+  auto load_halo = [&](const Tile& tl, v4i(&hreg)[NHL]) {
+    const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u / (2 * CG), part = u % (2 * CG);
+      const int hw = vox % I_HW;
+      const int t2 = vox / I_HW;
+      const int hh = t2 % I_HH, hd = t2 / I_HH;
+      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+      hreg[k] = v4i{0, 0, 0, 0};
+      if (u < G2_NH * 2 * CG && id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+        hreg[k] = *reinterpret_cast<const v4i*>(p.x + ((((size_t)tl.n * p.D + id) * p.H + ih) * p.W + iw) * p.C1 +
+                                                part * 16);
+    }
+  };
+  // targets: 64 voxels x 64 channels = 1024 float4, 4 per thread: u -> voxel u >> 4, channel quad u & 15
+  auto load_y = [&](const Tile& tl, float4(&yv)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u >> 4;
+      const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
+      yv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (od < p.OD && oh < p.OH && ow < p.OW)
+        yv[k] = *reinterpret_cast<const float4*>(p.y + ((((size_t)tl.n * p.OD + od) * p.OH + oh) * p.OW + ow) * p.C2 +
+                                                 ch0 + (u & 15) * 4);
+    }
+  };
+
+  const int hv = (plane * I_HH + (li >> 3)) * I_HW + (li & 7);
+  double l0 = 0.0;
+  v4i hreg[NHL];
+  float4 ynext[4], ycur[4];
+  if (t_begin < t_end) {
+    const Tile t0 = decode(t_begin);
+    load_halo(t0, hreg);
+    load_y(t0, ynext);
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      if (u < G2_NH * 2 * CG)
+        *reinterpret_cast<v4i*>(&halo[(u / (2 * CG)) * VS + ((u / (2 * CG)) / I_HW) * PADB + (u % (2 * CG)) * 16]) = hreg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ycur[k] = ynext[k];
+    lds_barrier();
+    if (tile + 1 < t_end) {
+      const Tile tn = decode(tile + 1);
+      load_halo(tn, hreg);
+      load_y(tn, ynext);
+    }
+    v16i acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0;
+    constexpr int NSTEP = 27 * CG;
+    v4i bq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bq[j] = wbase[(size_t)j * wstep];
+#pragma unroll 1
+    for (int s0 = 0; s0 < NSTEP; s0 += 8) {
+      const int t = s0 / CG, g0 = s0 % CG;                  // 8 | CG: the tap is constant inside a block of 8 steps
+      const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+      const int8_t* arow = halo + (hv + (kd * I_HH + kh) * I_HW + kw) * VS +
+                           (plane * I_HH + (li >> 3) + kd * I_HH + kh) * PADB + 16 * lh + 32 * g0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const v4i a = *reinterpret_cast<const v4i*>(arow + 32 * j);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[j], acc, 0, 0, 0);
+        int nxt = s0 + 8 + j;
+        nxt = (nxt < NSTEP) ? nxt : NSTEP - 1;              // unconditional load on a clamped index
+        bq[j] = wbase[(size_t)nxt * wstep];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      tb[(plane * 32 + i) * G2_TS + 32 * chalf + li] = (float)acc[r] * scale + bv;
+    }
+    lds_barrier();
+    const Tile tl = decode(tile);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = tid + k * 256;
+      const int vox = u >> 4, c4 = u & 15;
+      const int od = tl.od0 + (vox >> 5), oh = tl.oh0 + ((vox >> 3) & 3), ow = tl.ow0 + (vox & 7);
+      if (od < p.OD && oh < p.OH && ow < p.OW) {
+        const float4 o = *reinterpret_cast<const float4*>(&tb[vox * G2_TS + c4 * 4]);
+        const float d0 = o.x - ycur[k].x, d1 = o.y - ycur[k].y, d2 = o.z - ycur[k].z, d3 = o.w - ycur[k].w;
+        l0 += ((double)(d0 * d0) + (double)(d1 * d1)) + ((double)(d2 * d2) + (double)(d3 * d3));
+      }
+    }
+  }
+  double v[2] = {l0, l0};
+  grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
+                     gridDim.x * gridDim.y);
+}
+
 template <int CG>
 __global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Params p) {
   constexpr int VS = 32 * CG + 16;                         // bytes per halo voxel in LDS
@@ -1262,8 +1406,8 @@ static bool i8_two_plane(const effq_geom* g) {
 static int i8_plan(const effq_geom* g, I8Plan* pl) {
   EFFQ_CHECK_ARG(g != nullptr);
   EFFQ_CHECK_ARG(g->KD == 3 && g->KH == 3 && g->KW == 3 && g->SD == 1 && g->SH == 1 && g->SW == 1);
-  EFFQ_CHECK_ARG(g->C1 == 32 || g->C1 == 64 || g->C1 == 128 || g->C1 == 256);
-  EFFQ_CHECK_ARG(g->C2 > 0 && (g->C2 % 32) == 0);
+  EFFQ_CHECK_ARG(g->C1 == 32 || g->C1 == 64 || g->C1 == 128 || g->C1 == 256 || g->C1 == 512);
+  EFFQ_CHECK_ARG(g->C2 > 0 && (g->C2 % 32) == 0 && (g->C1 != 512 || (g->C2 % 64) == 0));
   EFFQ_CHECK_ARG(g->N > 0 && g->D > 0 && g->H > 0 && g->W > 0 && g->PD >= 0 && g->PH >= 0 && g->PW >= 0);
   ConvI8Params& p = pl->p;
   memset(&p, 0, sizeof(p));
@@ -1271,14 +1415,14 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
   p.PD = g->PD; p.PH = g->PH; p.PW = g->PW;
   p.OD = g->D + 2 * g->PD - 2; p.OH = g->H + 2 * g->PH - 2; p.OW = g->W + 2 * g->PW - 2;
   EFFQ_CHECK_ARG(p.OD > 0 && p.OH > 0 && p.OW > 0);
-  const int td = i8_two_plane(g) ? L2_TD : ITD;
+  const int td = i8_two_plane(g) ? L2_TD : (g->C1 == 512) ? G2_TD : ITD;
   p.tiles_d = (p.OD + td - 1) / td;
   p.tiles_h = (p.OH + ITH - 1) / ITH;
   p.tiles_w = (p.OW + ITW - 1) / ITW;
   const long long nt = (long long)p.N * p.tiles_d * p.tiles_h * p.tiles_w;
   EFFQ_CHECK_ARG(nt < (1ll << 30));
   p.ntiles = (int)nt;
-  const int ny = p.C2 / 32;
+  const int ny = (g->C1 == 512) ? p.C2 / 64 : p.C2 / 32;
   static const int wpc1 = getenv("EFFQ_I8_WPC") ? atoi(getenv("EFFQ_I8_WPC")) : 3;   // tuning aid (one-plane kernel)
   static const int wpc128 = getenv("EFFQ_I8_WPC128") ? atoi(getenv("EFFQ_I8_WPC128")) : 2;   // tuning aid
   static const int wpc64 = getenv("EFFQ_I8_WPC64") ? atoi(getenv("EFFQ_I8_WPC64")) : 2;      // tuning aid
@@ -1318,7 +1462,8 @@ extern "C" {
 int effq_conv_i8_supported(const effq_geom* g, int act_levels, int w_levels) {
   if (g == nullptr) return 0;
   if (!(g->KD == 3 && g->KH == 3 && g->KW == 3 && g->SD == 1 && g->SH == 1 && g->SW == 1)) return 0;
-  if (!(g->C1 == 32 || g->C1 == 64 || g->C1 == 128 || g->C1 == 256) || (g->C2 % 32) != 0) return 0;
+  if (!(g->C1 == 32 || g->C1 == 64 || g->C1 == 128 || g->C1 == 256 || g->C1 == 512) || (g->C2 % 32) != 0) return 0;
+  if (g->C1 == 512 && (g->C2 % 64) != 0) return 0;
   if (act_levels < 2 || act_levels > 128 || w_levels < 2 || w_levels > 128) return 0;
   // int32 accumulator range: 27*C1 products of at most (La-1)*(Lw-1)
   if ((double)27 * g->C1 * (act_levels - 1) * (w_levels - 1) >= 2147483647.0) return 0;
@@ -1482,7 +1627,13 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
     const int cg = p.C1 / 32;
     const size_t lds = (size_t)((I_NH * (32 * cg + 16) + I_HD * I_HH * halo_row_pad(cg) + 15) / 16) * 16 +
                        (size_t)128 * I_TS * sizeof(float);
-    if (cg == 2) {
+    if (cg == 16) {
+      const size_t lds2 = (size_t)((G2_NH * (32 * 16 + 16) + G2_HD * I_HH * halo_row_pad(16) + 15) / 16) * 16 +
+                          (size_t)64 * G2_TS * sizeof(float);
+      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_i8g2<16>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      hipLaunchKernelGGL(k_conv3d_i8g2<16>, pl.grid, dim3(256), lds2, st, p);
+    } else if (cg == 2) {
       EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_i8g<2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_conv3d_i8g<2>, pl.grid, dim3(256), lds, st, p);

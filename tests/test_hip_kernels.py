@@ -390,7 +390,8 @@ def test_single_launch_weight_fixed_point_matches_goldens(ops, gold, L):
                                              (256, 64, 16, 16, (4, 4, 8)), (128, 32, 16, 4, (5, 6, 9)),
                                              # 3 x 3 x 3 tiles: the centre tile takes the interior fast path
                                              (32, 32, 4, 4, (24, 12, 24)), (64, 64, 4, 4, (12, 12, 24)),
-                                             (64, 64, 16, 16, (12, 10, 24))])     # 64 ch, not tile-divisible
+                                             (64, 64, 16, 16, (12, 10, 24)),      # 64 ch, not tile-divisible
+                                             (512, 64, 4, 4, (4, 4, 8)), (512, 128, 16, 16, (3, 5, 9))])   # 2-plane tile
 def test_exact_int_conv_step_equals_fp32_path(ops, c1, c2, La, Lw, sp):
     """conv3d_calib_step_i8 (i8 MFMA, exact int32 accumulation) against conv3d_quant_calib_step on the
     SAME quantised operands: identical loss up to the fp32 path's own rounding (<= 2e-6 relative)."""
