@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from efficientq_amd.hip_ops import get_ops
 dev = "cuda:0"; ops = get_ops(dev)
-for n in (865, 3457, 6913):
+for n in ((865, 3457, 6913) if len(sys.argv) < 2 else tuple(int(v) for v in sys.argv[1:])):
     g = torch.Generator().manual_seed(n)
     X = torch.randn(n, 2 * n + 7, generator=g).to(dev)
     A0 = (2 * X @ X.T).contiguous()
