@@ -255,6 +255,139 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_c4h(DirectParams p, int tiles
   grid_sum_finish<2>(vsum, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
 }
 
+// ---- single-channel first conv (1 -> 32, 3^3: the LiTS nets, CT volumes) -----------------------------------------------------
+// The generic tiled kernel pads K = 27 to its 32-channel slabs and took 2.1 ms per evaluation on 8 x 160^3 volumes
+// (0.66 GB of input and targets).  Same scheme as k_conv3d_c4h: the input tile is staged through LDS (4 bytes per voxel),
+// K = 27 (+ 1 zero tap) runs as 14 v_mfma_f32_32x32x2_f32 steps - lane half h of step j contracts tap 2 j + h - and the
+// targets are read in MFMA layout.
+template <int SD, int SH, int SW>
+__global__ __launch_bounds__(256, 2) void k_conv3d_c1h(DirectParams p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
+  constexpr int HD = (C4_TD - 1) * SD + 3, HH = (C4_TH - 1) * SH + 3, HW = (C4_TW - 1) * SW + 3, NHV = HD * HH * HW;
+  constexpr int NHL = (NHV + 255) / 256;
+  constexpr int NJ = 14;                             // K steps of 2 taps
+  __shared__ float halo[NHV + 4];
+  __shared__ double red_smem[2 * 16];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+
+  float breg[NJ];
+  int toff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int tap = 2 * j + lh;
+    breg[j] = (tap < 27) ? p.G[(size_t)li * 27 + tap] : 0.0f;              // G [C2][1][27]
+    const int tc = (tap < 27) ? tap : 0;                                    // (the zero weight makes the 28th tap harmless)
+    const int kd = tc / 9, kh = (tc / 3) % 3, kw = tc % 3;
+    toff[j] = (kd * HH + kh) * HW + kw;
+  }
+  const float bv = (p.bias != nullptr) ? p.bias[li] : 0.0f;
+
+  int hcd[NHL], hch[NHL], hcw[NHL];
+  long long hrel[NHL];
+#pragma unroll
+  for (int k = 0; k < NHL; ++k) {
+    const int u = tid + k * 256;
+    const int v = (u < NHV) ? u : 0;
+    hcw[k] = v % HW;
+    const int t2 = v / HW;
+    hch[k] = t2 % HH;
+    const int hd = t2 / HH;
+    hcd[k] = (u < NHV) ? hd : (1 << 20);
+    hrel[k] = ((long long)hd * p.H + hch[k]) * p.W + hcw[k];
+  }
+  int yrel[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    yrel[r] = ((i >> 3) * p.OW + (i & 7)) * 32 + li;
+  }
+  const int abase = ((wid * SD) * HH + (li >> 3) * SH) * HW + (li & 7) * SW;
+
+  const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per;
+  const int t_end = (t_begin + per < ntiles) ? t_begin + per : ntiles;
+
+  float hreg[NHL];
+  float ynext[16], ycur[16];
+  unsigned hmask = 0, ymask_next = 0, ymask_cur = 0;
+  auto fetch = [&](int tile) {
+    int t = tile;
+    const int ow0 = (t % tiles_w) * C4_TW;
+    t /= tiles_w;
+    const int oh0 = (t % tiles_h) * C4_TH;
+    t /= tiles_h;
+    const int od0 = (t % tiles_d) * C4_TD;
+    const int n = t / tiles_d;
+    const int id0 = od0 * SD - p.PD, ih0 = oh0 * SH - p.PH, iw0 = ow0 * SW - p.PW;
+    const bool interior = id0 >= 0 && id0 + HD <= p.D && ih0 >= 0 && ih0 + HH <= p.H && iw0 >= 0 && iw0 + HW <= p.W &&
+                          od0 + C4_TD <= p.OD && oh0 + C4_TH <= p.OH && ow0 + C4_TW <= p.OW;
+    if (interior) {
+      const float* hb = p.x + (((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0;
+#pragma unroll
+      for (int k = 0; k < NHL; ++k) hreg[k] = hb[(hcd[k] < HD) ? hrel[k] : 0];
+      hmask = 0xffffffffu;
+      const float* yb = p.y + ((((long long)n * p.OD + od0 + wid) * p.OH + oh0) * p.OW + ow0) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ynext[r] = yb[yrel[r]];
+      ymask_next = 0xffffu;
+      return;
+    }
+    unsigned hm = 0;
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int id = id0 + hcd[k], ih = ih0 + hch[k], iw = iw0 + hcw[k];
+      const bool ok = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+      const int cd = min(max(id, 0), p.D - 1), chh = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
+      hm |= (ok ? 1u : 0u) << k;
+      hreg[k] = p.x[(((size_t)n * p.D + cd) * p.H + chh) * p.W + cw];
+    }
+    hmask = hm;
+    const int od = od0 + wid;
+    unsigned ym = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int oh = oh0 + (i >> 3), ow = ow0 + (i & 7);
+      const bool ok = od < p.OD && oh < p.OH && ow < p.OW;
+      ym |= (ok ? 1u : 0u) << r;
+      ynext[r] = p.y[((((size_t)n * p.OD + min(od, p.OD - 1)) * p.OH + min(oh, p.OH - 1)) * p.OW + min(ow, p.OW - 1)) * 32 + li];
+    }
+    ymask_next = ym;
+  };
+
+  double l0 = 0.0;
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int u = tid + k * 256;
+      if (u < NHV) halo[u] = ((hmask >> k) & 1u) ? hreg[k] : 0.0f;       // zero padding
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ycur[r] = ynext[r];
+    ymask_cur = ymask_next;
+    lds_barrier();
+    fetch((tile + 1 < t_end) ? tile + 1 : tile);
+    __builtin_amdgcn_sched_barrier(0);
+    d_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[abase + toff[j]], breg[j], acc, 0, 0, 0);
+    float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = (acc[r] + bv) - ycur[r];
+      s4[r & 3] = ((ymask_cur >> r) & 1u) ? __builtin_fmaf(d, d, s4[r & 3]) : s4[r & 3];
+    }
+    l0 += (double)((s4[0] + s4[1]) + (s4[2] + s4[3]));
+  }
+  double vsum[2] = {l0, l0};
+  grid_sum_finish<2>(vsum, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
+}
+
 // 1x1x1 conv onto C2 <= 16 channels on the f32 matrix cores (v_mfma_f32_16x16x4_f32; the classifier uses 3 of the 16
 // columns - the matrix cores are idle anyway and the dot products need no cross-lane reduction this way).  One wave-tile
 // = 16 voxels: lane (row = l & 15, kq = l >> 4) loads the C1/4 consecutive channels [kq C1/4, (kq+1) C1/4) of voxel `row`
@@ -312,6 +445,9 @@ __global__ __launch_bounds__(256) void k_conv1_mfma(DirectParams p) {
 
 int conv_direct_kind(const effq_geom* g) {
   if (g->C1 == 4 && g->C2 == 32 && g->KD == 3 && g->KH == 3 && g->KW == 3) return 1;
+  if (g->C1 == 1 && g->C2 == 32 && g->KD == 3 && g->KH == 3 && g->KW == 3 &&
+      ((g->SD == 1 && g->SH == 1 && g->SW == 1) || (g->SD == 2 && g->SH == 2 && (g->SW == 1 || g->SW == 2))))
+    return 3;
   if (g->KD == 1 && g->KH == 1 && g->KW == 1 && g->SD == 1 && g->SH == 1 && g->SW == 1 && g->PD == 0 && g->PH == 0 &&
       g->PW == 0 && g->C2 <= 4 && (g->C1 == 32 || g->C1 == 64 || g->C1 == 128 || g->C1 == 256))
     return 2;
@@ -321,6 +457,20 @@ int conv_direct_kind(const effq_geom* g) {
 int conv_direct_launch(int kind, DirectParams& p, size_t max_blocks, hipStream_t st) {
   if ((long long)p.N * p.D * p.H * p.W * p.C1 >= (1ll << 31) || p.V >= (1ll << 31)) return EFFQ_ERR_ARG;
   p.ntiles = (int)((p.V + 31) / 32);
+  if (kind == 3) {
+    const int td = (p.OD + C4_TD - 1) / C4_TD, th = (p.OH + C4_TH - 1) / C4_TH, tw = (p.OW + C4_TW - 1) / C4_TW;
+    const long long nt = (long long)p.N * td * th * tw;
+    if (nt >= (1ll << 30)) return EFFQ_ERR_ARG;
+    size_t grid = (size_t)nt < 512 ? (size_t)nt : 512;
+    if (grid > max_blocks) grid = max_blocks;
+    if (p.SD == 2 && p.SW == 2)
+      hipLaunchKernelGGL((k_conv3d_c1h<2, 2, 2>), dim3((unsigned)grid), dim3(256), 0, st, p, td, th, tw, (int)nt);
+    else if (p.SD == 2)
+      hipLaunchKernelGGL((k_conv3d_c1h<2, 2, 1>), dim3((unsigned)grid), dim3(256), 0, st, p, td, th, tw, (int)nt);   // LiTS
+    else
+      hipLaunchKernelGGL((k_conv3d_c1h<1, 1, 1>), dim3((unsigned)grid), dim3(256), 0, st, p, td, th, tw, (int)nt);
+    return EFFQ_OK;
+  }
   if (kind == 1 && p.SD == p.SH && p.SH == p.SW && (p.SD == 1 || p.SD == 2)) {
     static const int use_lds = getenv("EFFQ_C4_LDS") ? atoi(getenv("EFFQ_C4_LDS")) : 1;      // tuning aid
     if (use_lds) {

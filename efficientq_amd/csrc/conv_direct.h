@@ -17,7 +17,7 @@ struct DirectParams {
   double* sqerr;
 };
 
-// 0: not served; 1: 4-channel 3x3x3 conv onto 32 channels; 2: 1x1x1 conv onto <= 4 channels
+// 0: not served; 1: 4-channel 3x3x3 conv onto 32 channels; 2: 1x1x1 conv onto <= 4 channels; 3: 1-channel 3x3x3 conv onto 32
 int conv_direct_kind(const effq_geom* g);
 int conv_direct_launch(int kind, DirectParams& p, size_t max_blocks, hipStream_t st);
 

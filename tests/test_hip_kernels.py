@@ -290,6 +290,10 @@ CONV_CASES = [
     (64, 3, 1, 1, 0, (5, 6, 7)),        # classifier kernel: 64 channels, voxel count not a multiple of its 64-voxel body
     (128, 2, 1, 1, 0, (4, 4, 6)),
     (256, 4, 1, 1, 0, (3, 4, 5)),
+    (1, 32, 3, 2, 1, (24, 24, 48)),     # single-modality first conv (LiTS): LDS-staged kernel, interior + border tiles
+    (1, 32, 3, 2, 1, (10, 14, 18)),     # ragged output tiles
+    (1, 32, 3, 1, 1, (12, 12, 24)),     # stride 1
+    (1, 32, 3, (2, 2, 1), 1, (24, 24, 24)),   # the LiTS stride
 ]
 
 
@@ -316,7 +320,7 @@ def test_conv_step_vs_torch_fp32(ops, c1, c2, k, s, p, sp):
     # loss-only call (no output tensor) and no-mask call agree with the fused one
     _, sq2 = ops.conv_step(dev(_ndhwc(x)), dev(w), dev(b), geom, dev(_ndhwc(y)), None)
     sq2 = sq2.cpu()
-    if (c1 == 4 and c2 == 32 and k == 3) or (k == 1 and c2 <= 4 and c1 % 32 == 0):
+    if (c1 in (1, 4) and c2 == 32 and k == 3) or (k == 1 and c2 <= 4 and c1 % 32 == 0):
         # loss-only calls of these two layer shapes run the direct-gather kernels (conv3d_direct.hip):
         # a different fp32 summation order than the tiled kernel
         assert abs(sq2[0].item() - sq[0].item()) <= 2e-6 * sq[0].item() and sq2[1].item() == sq2[0].item()
