@@ -270,14 +270,24 @@ int effq_admm_run(const effq_admm_run_args* a) {
   hipEvent_t ev_fork = nullptr, ev_join_loss = nullptr, ev_join_side = nullptr;
 
   ADMM_HIP(hipMemsetAsync(a->dual, 0, nw * sizeof(float), s_main));                 // dual <- 0 (EfficientQConv.py:40)
-  // the inverse the first iterations need, on the main stream; the later ones on the side stream
+  // the inverse the first iterations need, on the main stream; the later ones on the side stream, which starts at once,
+  // beside the first inverse (all of them only read A0): with n = 13825 an inverse takes longer than the 50 iterations it has
+  // to be ready after, and the chain waited for each of the three later ones in turn (LiTS: 3.08 -> 3.03 s per calibration;
+  // BraTS 900 -> 893 ms).  EFFQ_SIDE_EARLY_N = smallest n that does so (tuning aid).
+  static const int early_n = getenv("EFFQ_SIDE_EARLY_N") ? atoi(getenv("EFFQ_SIDE_EARLY_N")) : 0;
+  const bool side_early = fork_side && n_inv > 1 && n >= early_n;
+  if (side_early) {
+    ADMM_HIP(new_event(&ev_fork));
+    ADMM_HIP(hipEventRecord(ev_fork, s_main));         // A0 (and everything before the call) is ready
+    ADMM_HIP(hipStreamWaitEvent(s_side, ev_fork, 0));
+  }
   {
     ProfScope ps(g_prof_every > 0, PROF_INVERSE, -1, a, s_main);
     ADMM_RC(effq_spd_inverse(a->A0, n, has_b, plan.rho[first], a->eta, a->ainv_pool, a->inv_ws, a->inv_ws_bytes, s_main));
     ps.close();
   }
   if (n_inv > 1) {
-    if (fork_side) {
+    if (fork_side && !side_early) {
       ADMM_HIP(new_event(&ev_fork));
       ADMM_HIP(hipEventRecord(ev_fork, s_main));       // A0 (and everything before the call) is ready
       ADMM_HIP(hipStreamWaitEvent(s_side, ev_fork, 0));
