@@ -262,6 +262,48 @@ def test_data_parallel_two_ranks_gloo_matches_single_rank(tmp_path):
     assert np.all(np.abs(a - b) <= 1e-3 * b), (a, b)
 
 
+def _bench(*flags, env=None, timeout=600):
+    e = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    e.pop("WORLD_SIZE", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=e, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_starts_its_own_ranks_for_gpus_above_one():
+    """`python bench.py --gpus N` (the driver's command form) must launch N ranks itself, run a real all-reduce over
+    them and relay exactly ONE JSON line; here on gloo / CPU, without any calibration (--spawn-check)."""
+    import json
+    r = _bench("--gpus", "2", "--spawn-check")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus_and_relays_child_failure():
+    # under a launcher (WORLD_SIZE set) --gpus must equal the world size
+    r = _bench("--gpus", "4", "--spawn-check", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    # a failing rank makes the parent exit non-zero and print no result line (no GPU here: the ranks cannot calibrate)
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_bench_config_presets():
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    a = bench.parse_args([])
+    assert (a.net, a.levels, a.vols, a.size, a.gpus) == ("brats", 4, 16, 128, 1)       # BASELINE configs[1]
+    a = bench.parse_args(["--config", "3"])
+    assert (a.net, a.levels, a.vols, a.size) == ("brats", 16, 8, 128)                  # configs[2]
+    a = bench.parse_args(["--config", "4", "--vols", "2"])
+    assert (a.net, a.levels, a.vols, a.size) == ("lits", 4, 2, 160)                    # configs[3], flag override
+
+
 @pytest.mark.parametrize("tag,psz,ov", [("a", 6, 2), ("b", (6, 12, 6), (2, 0, 3)), ("c", 7, 3)])
 def test_sliding_window_helpers_match_reference(gold, tag, psz, ov):
     """Row f1 host logic (efficientq_amd/evaluate.py) against the reference's split / stitch / Dice goldens."""
