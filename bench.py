@@ -106,6 +106,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_I8_MFMA_TOPS = 5033.2        # MI355X dense int8 matrix peak (MI355X_MICROARCH.md: = fp8 dense)
 PEAK_F64_MFMA_TFLOPS = 78.6       # MI355X fp64 matrix peak (vendor)
+PEAK_BF16_MFMA_TFLOPS = 2516.6    # MI355X dense bf16 matrix peak (MI355X_MICROARCH.md: ~2.5 PF dense = 16 x the f32 rate)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 NET_TFLOP_PER_VOLUME = 24.55      # conv 21.59 + Gram 2.96 TFLOP per 4x128^3 volume (fp32 algorithmic work)
 SAMPLE = 4                        # one launch / iteration in SAMPLE is bracketed by HIP events
@@ -234,11 +235,17 @@ class OpTimer:
             return ("mfma", 1.0 * n ** 3, PEAK_F64_MFMA_TFLOPS, "TFLOP/s",
                     f"k_gj_* (n={n}, n^3 fp64 flop: symmetric sweep, upper triangle only)")
         if op == "prox":
-            if c2 >= 256 and n >= 2048:
-                # the 256-row GEMM kernel is > 97 % of this bracket (the split-K reduce takes 5 us, the right-hand side is
-                # written by the projection kernel of the previous iteration): reported as a single-kernel op
-                return ("mfma", 2.0 * c2 * n * n, PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
-                        f"k_prox_gemm<2,4,1,2> (+ 5 us k_prox_reduce4) (c2={c2}, n={n}; 2 c2 n^2 flop, f32 MFMA)")
+            if c2 > 64 and n >= 1024:
+                # the GEMM kernel is > 95 % of this bracket (the split-K reduce takes ~5 us, the right-hand side is
+                # written by the projection kernel of the previous iteration): reported as a single-kernel op.
+                # It runs on the bf16 matrix cores with both fp32 operands split in three (six exact bf16 products per
+                # fp32 product, fp32 accumulate): the flops it EXECUTES are 6 x 2 c2 n^2, and that is
+                # what is set against the dense bf16 peak
+                tile = "256,256,4,2" if c2 > 128 else "128,256,2,4"
+                return ("mfma", 6.0 * 2.0 * c2 * n * n, PEAK_BF16_MFMA_TFLOPS, "TFLOP/s",
+                        f"k_prox_gemm_b3<{tile}> (+ ~5 us k_prox_reduce4) (c2={c2}, n={n}: the fp32 product 2 c2 n^2 = "
+                        f"{2.0 * c2 * n * n / 1e9:.2f} GFLOP evaluated as 6 bf16 MFMA products of operands split in "
+                        f"three, {12.0 * c2 * n * n / 1e9:.1f} GFLOP executed)")
             return ("mfma", 2.0 * c2 * n * n, PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                     f"k_prox_gemm + k_prox_reduce (c2={c2}, n={n}; 2 c2 n^2 flop)")
         nw = c2 * (n - 1)
@@ -280,7 +287,7 @@ class OpTimer:
                              timed_launches=len(ms), avg_ms=round(avg, 4), total_ms=round(avg * launches, 1),
                              ms_per_step=round(avg * launches / steps, 1), work_per_launch=work,
                              composite=(key[0] in ("inverse", "fixed_point") or
-                                        (key[0] == "prox" and not (key[1] >= 256 and key[2] >= 2048)))))
+                                        (key[0] == "prox" and not (key[1] > 64 and key[2] >= 1024)))))
         rows.sort(key=lambda r: -r["total_ms"])
         for r in rows:
             log(f"[ops] {r['total_ms']:9.1f} ms {r['launches']:6d} x {r['avg_ms']:9.4f} ms  {r['frac']:.3f} of {r['bound']} "

@@ -102,7 +102,10 @@ SIGNATURES = {
     "effq_alpha_fixed_point": (_I, [_P, _SZ, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
     "effq_fp_small_max": (_SZ, []),
     "effq_fixed_point_small": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P]),
+    "effq_fp_sorted_max": (_SZ, []),
+    "effq_fixed_point_sorted": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P]),
     "effq_fp_coop_max": (_SZ, []),
+    "effq_fp_coop_set_spin_limit": (_I, [C.c_uint]),
     "effq_fixed_point_coop": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _P]),
     "effq_fp_bucket_max": (_SZ, []),
     "effq_fp_bucket_ws_bytes": (_SZ, [_SZ]),
@@ -130,6 +133,9 @@ SIGNATURES = {
     "effq_gram_accum_i8": (_I, [_P, _P, _GP, _I, _P, _I, _P, _P, _P, _I, _LL, _P, _P, _I, _P, _SZ, _P]),
     "effq_gram_accum_i8_unw": (_I, [_P, _P, _GP, _I, _P, _I, _P, _P, _P, _I, _LL, _P, _P, _I, _P, _P, _P, _SZ, _P]),
     "effq_upsample_trilinear": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "effq_gram_f64_supported": (_I, [_GP, _I]),
+    "effq_gram_f64_ws_bytes": (_SZ, [_GP, _I]),
+    "effq_gram_f64": (_I, [_P, _P, _GP, _I, _P, _P, _P, _SZ, _P]),
     "effq_gram_loss_ws_bytes": (_SZ, [_I]),
     "effq_gram_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "effq_packed_bytes": (_SZ, [_SZ, _I]),

@@ -396,6 +396,267 @@ __global__ __launch_bounds__(T) void k_fp_small(const float* __restrict__ a, con
   }
 }
 
+// ---- whole project_by_iter on SORTED values, for many-level quantisers on small tensors ------------------------
+// At 256 levels (first / last conv, q_first = q_last = "256,-1") the fixed point takes ~300 iterations per call and is
+// called 200 times per layer: the per-iteration LATENCY is what counts (k_fp_small: 1.3 us = per-value work + two wave
+// reductions + a workgroup barrier + two fp64 divisions).  Here the values are sorted once (bitonic, LDS) with fp64
+// prefix sums P[i] = sum of the i smallest; the level function is monotone in v, so the values of level index >= k
+// start at a position pos_k, and
+//     sum r v = (L-1) P[n] - sum_k P[pos_k],   sum r = (L-1) n - sum_k pos_k,   sum r^2 = (L-1)^2 n - sum_k (2k-1) pos_k
+// (k = 1..L-1) feed the same expressions as k_fp_small.  ONE wave iterates, lane = boundary (KB per lane): no barrier,
+// no cross-wave traffic.  pos_k is re-found from its previous value: the boundaries creep as alpha converges, so almost
+// every check is "still between the same two neighbours" (two LDS reads); otherwise a galloping + binary search.
+// The predicate "level index of v >= k" is the fp32 evaluation of u = (v/alpha - lo)/d unless u lies within 2e-4 of the
+// rounding boundary k - 1/2, where the reference's own fp64 arithmetic (disc64) decides: positions - and therefore
+// the integer sums - are exactly the reference's; sum r v differs from a sequential fp64 sum by rounding order only.
+constexpr int FPSORT_T = 1024;
+constexpr int FPSORT_MAXN = 4096;
+
+template <int KB>
+__global__ __launch_bounds__(FPSORT_T) void k_fp_sorted(const float* __restrict__ a, const float* __restrict__ b2,
+                                                        float* __restrict__ v_out, int n, int P, int levels,
+                                                        effq_fp_state* st, double lo, double hi, double d, double tol,
+                                                        int max_iter) {
+  __shared__ float sv[FPSORT_MAXN];
+  __shared__ double pre[FPSORT_MAXN + 1];
+  __shared__ double part[2][FPSORT_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // ---- load v = a + b2, sum |v| ----
+  double acc0 = 0.0;
+  for (int i = tid; i < P; i += FPSORT_T) {
+    float v = __builtin_inff();
+    if (i < n) {
+      v = (b2 != nullptr) ? (a[i] + b2[i]) : a[i];
+      if (v_out != nullptr) v_out[i] = v;
+      acc0 += fabs((double)v);
+    }
+    sv[i] = v;
+  }
+  acc0 = wave_sum_f64_dpp(acc0);
+  if (lane == 0) part[0][wid] = acc0;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int w = 0; w < FPSORT_T / 64; ++w) tot += part[0][w];
+  // ---- bitonic sort, ascending (the +inf padding ends up behind the n values) ----
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (P >> 1); t += FPSORT_T) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const bool up = (i & k) == 0;
+        const float x = sv[i], y = sv[l];
+        if ((x > y) == up) {
+          sv[i] = y;
+          sv[l] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- fp64 prefix sums pre[i] = sum of the i smallest values: thread t owns the chunk [t C, (t+1) C); the chunk
+  // totals are scanned (Hillis-Steele, fixed order) in two scratch rows taken from `pre`, which is written afterwards
+  {
+    const int C = (P + FPSORT_T - 1) / FPSORT_T;         // 1, 2 or 4 (P is a power of two >= 64)
+    const int nch = P / C;                               // <= 1024 chunks
+    double loc = 0.0;
+    if (tid < nch)
+      for (int q = 0; q < C; ++q) {
+        const int i = tid * C + q;
+        if (i < n) loc += (double)sv[i];
+      }
+    double* src = pre;
+    double* dst = pre + FPSORT_T;
+    if (tid < nch) src[tid] = loc;
+    __syncthreads();
+    for (int off = 1; off < nch; off <<= 1) {
+      if (tid < nch) dst[tid] = src[tid] + (tid >= off ? src[tid - off] : 0.0);
+      __syncthreads();
+      double* sw = src;
+      src = dst;
+      dst = sw;
+    }
+    const double excl = (tid < nch && tid > 0) ? src[tid - 1] : 0.0;    // total of the chunks before this one
+    __syncthreads();                                     // every scan value has been read: pre may be overwritten
+    if (tid < nch) {
+      double run = excl;
+      for (int q = 0; q < C; ++q) {
+        const int i = tid * C + q;
+        if (i <= n) pre[i] = run;
+        if (i < n) run += (double)sv[i];
+      }
+      if (tid * C + C == n) pre[n] = run;                // (n == P, or n at a chunk end: same value as the next chunk's)
+    }
+    __syncthreads();
+  }
+  if (wid != 0) return;
+  // ---- the fixed point, one wave ----
+  __builtin_amdgcn_s_setprio(3);
+  const int L1 = levels - 1;
+  const double rd = 1.0 / d;
+  const float c0 = (float)(-lo * rd);
+  double alpha = tot / (double)n, alpha_prev = -999.0;
+  float c1 = (float)(((double)n / tot) * rd);
+  auto pred = [&](int i, int kidx) -> bool {             // level index of the i-th smallest value >= kidx ?
+    if (i < 0) return false;
+    if (i >= n) return true;
+    const float vf = sv[i];
+    const float u = __builtin_fmaf(vf, c1, c0);
+    const float thr = (float)kidx - 0.5f;
+    if (fabsf(u - thr) > 2e-4f) return u > thr;           // (NaN: falls through to the exact path)
+    double r;
+    disc64((double)vf, alpha, lo, hi, d, &r);
+    return r >= (double)kidx;
+  };
+  // Per boundary the lane keeps, beside the position, the interval [alo, ahi] of alpha over which that position is
+  // CERTAINLY still right - the value at pos at least 1e-9 level units above the rounding boundary, the value below pos
+  // at least 1e-9 under it (fp64 evaluates u to ~1e-13) - so that an iteration whose alpha stays inside touches no memory
+  // at all for that boundary.  A position that cannot be certified (a value within 1e-9 of the boundary, zeros at the
+  // middle boundary of an even level count) gets the empty interval and is re-checked by pred() every iteration.
+  constexpr double MARGIN = 1e-9, INF = __builtin_huge_val();
+  auto certify = [&](int p, int kidx, double& alo, double& ahi) {
+    const double T = lo + ((double)kidx - 0.5) * d;        // boundary in units of v / alpha
+    const double Tp = T + MARGIN * d, Tm = T - MARGIN * d;
+    alo = 0.0;
+    ahi = INF;
+    if (p < n) {                                           // v[p] / alpha >= Tp
+      const double v = (double)sv[p];
+      if (Tp > 0.0) {
+        if (v > 0.0) ahi = fmin(ahi, (v / Tp) * (1.0 - 1e-12)); else alo = INF;
+      } else if (Tp < 0.0) {
+        if (v < 0.0) alo = fmax(alo, (v / Tp) * (1.0 + 1e-12));
+      } else if (!(v >= 0.0)) {
+        alo = INF;
+      }
+    }
+    if (p > 0) {                                           // v[p - 1] / alpha <= Tm
+      const double v = (double)sv[p - 1];
+      if (Tm > 0.0) {
+        if (v > 0.0) alo = fmax(alo, (v / Tm) * (1.0 + 1e-12));
+      } else if (Tm < 0.0) {
+        if (v < 0.0) ahi = fmin(ahi, (v / Tm) * (1.0 - 1e-12)); else alo = INF;
+      } else if (!(v <= 0.0)) {
+        alo = INF;
+      }
+    }
+  };
+  int pos[KB];
+  double alo[KB], ahi[KB];
+#pragma unroll
+  for (int kk = 0; kk < KB; ++kk) {
+    const int kidx = 1 + lane + 64 * kk;
+    int lo_i = -1, hi_i = n;                             // pred(lo_i) false, pred(hi_i) true
+    alo[kk] = 0.0;
+    ahi[kk] = INF;
+    if (kidx <= L1) {
+      while (hi_i - lo_i > 1) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (pred(mid, kidx)) hi_i = mid; else lo_i = mid;
+      }
+      certify(hi_i, kidx, alo[kk], ahi[kk]);
+    }
+    pos[kk] = hi_i;
+  }
+  const double svt = pre[n];
+  const double lo_sv = lo * svt, lo2n = lo * lo * (double)n, d2 = d * d, dlo2 = 2.0 * d * lo;
+  const double rv_top = (double)L1 * svt;
+  const long long r_top = (long long)L1 * n, r2_top = (long long)L1 * L1 * n;
+  // this lane's share of sum_k P[pos_k], sum_k pos_k, sum_k (2k-1) pos_k: recomputed only when one of its positions moves
+  double sp = 0.0;
+  unsigned sr = 0, sr2 = 0;
+  auto lane_sums = [&]() {
+    sp = 0.0;
+    sr = 0;
+    sr2 = 0;
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      const int kidx = 1 + lane + 64 * kk;
+      if (kidx <= L1) {
+        const int p = pos[kk];
+        sp += pre[p];
+        sr += (unsigned)p;
+        sr2 += (unsigned)((2 * kidx - 1) * p);
+      }
+    }
+  };
+  lane_sums();
+  double last0 = 0.0, last1 = 0.0;
+  int it = 0, done = 0;
+  while (!done) {
+    const double wsp = wave_sum_f64_dpp(sp);
+    // (the integer sums ride the fp64 DPP tree too: exact below 2^53.  A build that summed them with group_sum_u32 and
+    // instantiated one boundary per lane produced wrong totals on gfx950 although every variation of the surrounding
+    // code - this one included - gives the right ones: kept to the shape that is tested over the whole level range)
+    const double tr = (double)r_top - wave_sum_f64_dpp((double)sr);
+    const double tr2 = (double)r2_top - wave_sum_f64_dpp((double)sr2);
+    const double trv = rv_top - wsp;
+    const double t0 = d * trv + lo_sv;                         // sum b v
+    const double t1 = (d2 * tr2 + dlo2 * tr) + lo2n;           // sum b^2
+    const double a_new = t0 / t1;
+    ++it;
+    if (it >= max_iter)
+      done = 2;
+    else if (!(fabs(a_new - alpha) > tol))
+      done = 1;
+    alpha_prev = alpha;
+    alpha = a_new;
+    last0 = t0;
+    last1 = t1;
+    if (done) break;
+    // positions under the new alpha: only the boundaries whose certified interval alpha has left
+    bool moved = false;
+    bool c1_ready = false;
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      const int kidx = 1 + lane + 64 * kk;
+      if (kidx <= L1 && !(alpha >= alo[kk] && alpha <= ahi[kk])) {
+        if (!c1_ready) {
+          c1 = (float)((1.0 / alpha) * rd);
+          c1_ready = true;
+        }
+        const int p = pos[kk];
+        int lo_i, hi_i;
+        if (pred(p, kidx)) {                               // pos <= p: gallop down
+          hi_i = p;
+          lo_i = p - 1;
+          int step = 1;
+          while (lo_i >= 0 && pred(lo_i, kidx)) {
+            hi_i = lo_i;
+            lo_i -= step;
+            step <<= 1;
+          }
+          if (lo_i < -1) lo_i = -1;
+        } else {                                           // pos > p: gallop up
+          lo_i = p;
+          hi_i = p + 1;
+          int step = 1;
+          while (hi_i < n && !pred(hi_i, kidx)) {
+            lo_i = hi_i;
+            hi_i += step;
+            step <<= 1;
+          }
+          if (hi_i > n) hi_i = n;
+        }
+        while (hi_i - lo_i > 1) {
+          const int mid = (lo_i + hi_i) >> 1;
+          if (pred(mid, kidx)) hi_i = mid; else lo_i = mid;
+        }
+        moved = moved || (hi_i != p);
+        pos[kk] = hi_i;
+        certify(hi_i, kidx, alo[kk], ahi[kk]);
+      }
+    }
+    if (moved) lane_sums();
+  }
+  if (lane == 0) {
+    st->alpha = alpha;
+    st->alpha_prev = alpha_prev;
+    st->sums[0] = last0;
+    st->sums[1] = last1;
+    st->iters = it;
+    st->done = done;
+  }
+}
+
 // ---- cooperative whole-fixed-point kernel for larger tensors --------------------------------------
 // G <= 256 workgroups of 1024 threads, one per CU, each owning a contiguous slice of v that stays in LDS for
 // all iterations.  Per iteration every workgroup publishes its two partial sums, all meet at a grid
@@ -408,8 +669,13 @@ constexpr int FPC_T = 1024;
 constexpr int FPC_SLICE = 27648;          // floats per workgroup kept in LDS (108 KiB)
 constexpr int FPC_MAXG = 256;          // one workgroup per CU at most: 7.08 M values = 512 x 512 x 27 weights
 constexpr unsigned FPC_SPIN_LIMIT = 1u << 24;
+static unsigned g_fpc_spin_limit = FPC_SPIN_LIMIT;     // effq_fp_coop_set_spin_limit (test hook)
 
-__device__ __forceinline__ bool fpc_barrier(unsigned int* counter, unsigned target, int* s_fail) {
+// counter[0] = arrivals, counter[1] = check-outs, counter[2] = POISON: set by the first workgroup whose barrier times
+// out.  A poisoned workspace turns every later launch into a no-op that reports done = 3 (the launches of the following
+// ADMM iterations are already enqueued when a time-out happens, and the arrival counter is left non-zero by the early
+// exits: they must not run on it); the host clears the workspace when it sees the error (qconv.ptq).
+__device__ __forceinline__ bool fpc_barrier(unsigned int* counter, unsigned target, int* s_fail, unsigned spin_limit) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -418,7 +684,9 @@ __device__ __forceinline__ bool fpc_barrier(unsigned int* counter, unsigned targ
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > FPC_SPIN_LIMIT) {
+      if (++spins > spin_limit ||
+          __hip_atomic_load(counter + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(counter + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_fail = 1;
         break;
       }
@@ -434,8 +702,14 @@ template <int T>
 __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, const float* __restrict__ b2,
                                                    float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
                                                    double hi, double d, double tol, int max_iter, double* partials,
-                                                   unsigned int* counter) {
+                                                   unsigned int* counter, unsigned spin_limit) {
   __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+  // a workspace poisoned by an earlier time-out: report and leave, touching nothing (uniform across the grid: the
+  // poison word only ever goes 0 -> 1 before this launch started, or during it - then the barrier below catches it)
+  if (__hip_atomic_load(counter + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->done = 3;
+    return;
+  }
 
   extern __shared__ __attribute__((aligned(16))) float vs[];      // this workgroup's slice of v
   constexpr int NW = T / 64;
@@ -487,8 +761,8 @@ __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, cons
     partials[(0 * FPC_MAXG + wg) * 3 + 1] = acc1;
     partials[(0 * FPC_MAXG + wg) * 3 + 2] = 0.0;
   }
-  if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail)) {
-    if (wg == 0 && tid == 0) st->done = 3;
+  if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail, spin_limit)) {
+    if (tid == 0) st->done = 3;          // (any workgroup: workgroup 0 may have left through the poison check)
     return;
   }
   // the G partials are fetched by the lanes of wave 0 (agent-scope loads, lane l takes workgroups l, l + 64, ...) and
@@ -553,8 +827,8 @@ __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, cons
       partials[(par * FPC_MAXG + wg) * 3 + 1] = dr;
       partials[(par * FPC_MAXG + wg) * 3 + 2] = dr2;
     }
-    if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail)) {
-      if (wg == 0 && tid == 0) st->done = 3;
+    if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail, spin_limit)) {
+      if (tid == 0) st->done = 3;
       return;
     }
     double trv = 0.0, tr = 0.0, tr2 = 0.0;
@@ -933,6 +1207,22 @@ int effq_alpha_fixed_point(const float* x, size_t n, int levels, double lo, doub
 }
 
 size_t effq_fp_small_max(void) { return (size_t)1 << 15; }
+size_t effq_fp_sorted_max(void) { return (size_t)FPSORT_MAXN; }
+
+int effq_fixed_point_sorted(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                            double tol, int max_iter, effq_fp_state* state_dev, void* stream) {
+  EFFQ_CHECK_ARG(a && state_dev && n > 0 && levels >= 2 && levels <= 256 && hi > lo && max_iter > 0);
+  EFFQ_CHECK_ARG(n <= effq_fp_sorted_max());
+  EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
+  const double d = (hi - lo) / (double)(levels - 1);
+  int P = 64;
+  while ((size_t)P < n) P <<= 1;
+  // one instantiation (4 boundary slots per lane of the iterating wave cover 255 boundaries; unused slots are skipped)
+  hipLaunchKernelGGL((k_fp_sorted<4>), dim3(1), dim3(FPSORT_T), 0, as_stream(stream), a, b, v_out, (int)n, P, levels,
+                     state_dev, lo, hi, d, tol, max_iter);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
 
 int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                            double tol, int max_iter, effq_fp_state* state_dev, void* stream) {
@@ -940,6 +1230,10 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
   EFFQ_CHECK_ARG(n <= effq_fp_small_max());
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
   const double d = (hi - lo) / (double)(levels - 1);
+  // many levels on a small tensor: the sorted-value kernel (effq_fixed_point_sorted) where it is the faster one
+  static const int sorted_on = getenv("EFFQ_FP_SORTED") ? atoi(getenv("EFFQ_FP_SORTED")) : 0;   // A/B switch
+  if (sorted_on && levels >= 32 && levels <= 256 && n <= (size_t)FPSORT_MAXN)
+    return effq_fixed_point_sorted(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, stream);
   {
     // threads: 256 up to 2048 elements, 512 up to 16384 (few waves: the barrier is cheap and the element loop stays
     // short; measured best on MI355X, scripts/exp_fp256.py), else 1024; slots per thread rounded up to a power of 2.  EFFQ_FPS_T overrides (tuning aid).
@@ -1004,7 +1298,11 @@ static int fixed_point_coop_impl(const float* a, const float* b, float* v_out, s
                                                           sizeof(double) * RED_MAX_BLOCKS * RED_SLOTS + 64);
   hipStream_t st = as_stream(stream);
   // (the kernel leaves its two counter words at zero; the reduction workspace is zero-filled at creation)
-  static bool attr_set = false;
+  int dev = 0;
+  EFFQ_HIP(hipGetDevice(&dev));
+  EFFQ_CHECK_ARG(dev >= 0 && dev < 64);
+  static bool attr_set_dev[64] = {};
+  bool& attr_set = attr_set_dev[dev];
   if (!attr_set) {
     EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fp_coop<FPC_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(FPC_SLICE * sizeof(float))));
@@ -1015,10 +1313,12 @@ static int fixed_point_coop_impl(const float* a, const float* b, float* v_out, s
   // The grid barrier needs every workgroup resident at once.  That holds on a whole MI355X (G <= 256 = its CU count,
   // one workgroup per CU by LDS); on a partitioned device (CPX / DPX), a smaller part, or with the CUs shared, it may
   // not: then the fixed point runs as one launch per iteration (each a no-op once converged) - slower, never stuck.
-  static int resident_max[2] = {-1, -1};
-  if (resident_max[light] < 0) {
-    int dev = 0, ncu = 0, per_cu = 0;
-    EFFQ_HIP(hipGetDevice(&dev));
+  static int resident_max_dev[64][2];
+  static bool resident_known[64][2] = {};
+  int* resident_max = resident_max_dev[dev];
+  if (!resident_known[dev][light]) {
+    resident_known[dev][light] = true;
+    int ncu = 0, per_cu = 0;
     EFFQ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (light)
       EFFQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fp_coop<512>, 512, FPC_SLICE / 2 * sizeof(float)));
@@ -1046,11 +1346,16 @@ static int fixed_point_coop_impl(const float* a, const float* b, float* v_out, s
   }
   if (light)
     hipLaunchKernelGGL(k_fp_coop<512>, dim3(G), dim3(512), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol, max_iter,
-                       partials, counter);
+                       partials, counter, g_fpc_spin_limit);
   else
     hipLaunchKernelGGL(k_fp_coop<FPC_T>, dim3(G), dim3(FPC_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol,
-                       max_iter, partials, counter);
+                       max_iter, partials, counter, g_fpc_spin_limit);
   EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_fp_coop_set_spin_limit(unsigned int polls) {
+  g_fpc_spin_limit = polls ? polls : FPC_SPIN_LIMIT;
   return EFFQ_OK;
 }
 

@@ -49,24 +49,17 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 16 waves, 4 columns of the 64 x 64 block per wave (lane = row): a pivot step costs every wave 4 column updates
-// (the 4-wave version, 16 columns per wave, took 32 us per block - 64 serial steps of ~1500 cycles - on the critical
-// path of every inverse).
-constexpr int GJD_T = 1024, GJD_CPW = NBK / (GJD_T / 64);     // columns per wave = 4
-__global__ __launch_bounds__(GJD_T) void k_gj_diag(const double* __restrict__ A, int npad, int kb,
-                                                   double* __restrict__ Dinv) {
-  __shared__ double fcol[2][NBK + 1];   // [parity][row] multipliers, [NBK] = 1/pivot
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  double reg[GJD_CPW];
-#pragma unroll
-  for (int j = 0; j < GJD_CPW; ++j) reg[j] = A[(size_t)(kb + lane) * npad + kb + wid * GJD_CPW + j];
+// In-register Gauss-Jordan inverse of a 64 x 64 block held as lane = row, wave w = columns CPW w .. CPW w + CPW - 1
+// (64 / CPW waves take part).  fcol: [2][NBK + 1] doubles of LDS.
+template <int CPW>
+__device__ __forceinline__ void gj_invert_regs(double (&reg)[CPW], double (*fcol)[NBK + 1], int lane, int wid) {
 #pragma unroll
   for (int p = 0; p < NBK; ++p) {      // fully unrolled: pivot column / lane selectors become immediates
-    const int par = p & 1, wp = p / GJD_CPW, jp = p % GJD_CPW;
+    const int par = p & 1, wp = p / CPW, jp = p % CPW;
     if (wid == wp) {
       double cp = reg[0];
 #pragma unroll
-      for (int j = 1; j < GJD_CPW; ++j) cp = (jp == j) ? reg[j] : cp;
+      for (int j = 1; j < CPW; ++j) cp = (jp == j) ? reg[j] : cp;
       fcol[par][lane] = cp;
       if (lane == p) fcol[par][NBK] = 1.0 / cp;
     }
@@ -74,7 +67,7 @@ __global__ __launch_bounds__(GJD_T) void k_gj_diag(const double* __restrict__ A,
     const double piv = fcol[par][NBK];
     const double f = fcol[par][lane];
 #pragma unroll
-    for (int j = 0; j < GJD_CPW; ++j) {
+    for (int j = 0; j < CPW; ++j) {
       const double rp = readlane_f64(reg[j], p) * piv;      // scaled pivot-row entry of this column
       const bool colp = (wid == wp) && (jp == j);
       double v;
@@ -85,6 +78,21 @@ __global__ __launch_bounds__(GJD_T) void k_gj_diag(const double* __restrict__ A,
       reg[j] = v;
     }
   }
+}
+
+// 16 waves, 4 columns of the 64 x 64 block per wave (lane = row): a pivot step costs every wave 4 column updates
+// (the 4-wave version, 16 columns per wave, took 32 us per block - 64 serial steps of ~1500 cycles - on the critical
+// path of every inverse).  Only the FIRST pivot block of an inverse is inverted by this kernel: the later ones are
+// inverted by a workgroup of the preceding trailing update (k_gj_trail_sym), under that update.
+constexpr int GJD_T = 1024, GJD_CPW = NBK / (GJD_T / 64);     // columns per wave = 4
+__global__ __launch_bounds__(GJD_T) void k_gj_diag(const double* __restrict__ A, int npad, int kb,
+                                                   double* __restrict__ Dinv) {
+  __shared__ double fcol[2][NBK + 1];   // [parity][row] multipliers, [NBK] = 1/pivot
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double reg[GJD_CPW];
+#pragma unroll
+  for (int j = 0; j < GJD_CPW; ++j) reg[j] = A[(size_t)(kb + lane) * npad + kb + wid * GJD_CPW + j];
+  gj_invert_regs<GJD_CPW>(reg, fcol, lane, wid);
 #pragma unroll
   for (int j = 0; j < GJD_CPW; ++j) Dinv[lane * NBK + wid * GJD_CPW + j] = reg[j];
 }
@@ -190,16 +198,72 @@ __global__ __launch_bounds__(256) void k_gj_panel(double* __restrict__ A, int np
       }
 }
 
+// blockIdx.y = 0 is the LOOK-AHEAD row: its first workgroup forms the pivot block of the NEXT step - tile (k+1, k+1)
+// after this step's update, which it computes itself from the not yet updated tile (the regular workgroups leave that
+// tile alone: k_gj_panel of the next step overwrites it with its inverse anyway) - and inverts it in registers, while the
+// other workgroups update the rest of the triangle.  The 64 serial pivots (~30 us with 4 waves) that used to sit
+// between two trailing updates as a kernel of their own (k_gj_diag: 24 us + a launch gap per 64 columns) are hidden
+// under the update.  blockIdx.y = ib + 1 for the regular rows.
 __global__ __launch_bounds__(256) void k_gj_trail_sym(double* __restrict__ A, int npad, int kb,
-                                                      const double* __restrict__ NZ, const double* __restrict__ XT) {
+                                                      const double* __restrict__ NZ, const double* __restrict__ XT,
+                                                      double* __restrict__ Dinv_next) {
   __shared__ __attribute__((aligned(16))) double As[NBK * LDA_S];
+  __shared__ double fcol[2][NBK + 1];
   const int kblk = kb / NBK, nblk = npad / NBK;
-  const int ib = blockIdx.y;
-  if (ib == kblk) return;
-  if ((int)(blockIdx.x * GJ_CT + GJ_CT - 1) < ib) return;        // the whole strip lies below the diagonal
+  const int kn = kblk + 1;                                         // the next pivot block
+  const bool ahead = Dinv_next != nullptr && kn < nblk;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int lr = lane & 15, lk = lane >> 4;
+  if (blockIdx.y == 0) {
+    if (blockIdx.x != 0 || !ahead) return;
+    for (int e = tid; e < NBK * NBK; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      As[r * LDA_S + c] = NZ[(size_t)(kn * NBK + r) * NBK + c];      // -Z_kn
+    }
+    lds_barrier();
+    const double* Cb = A + (size_t)(kn * NBK + wr * 32) * npad + (size_t)kn * NBK + wc * 32;
+    const double* Rb = XT + (size_t)kn * NBK + wc * 32;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = Cb[(size_t)(mi * 16 + lk + 4 * r) * npad + ni * 16 + lr];
+#pragma unroll 4
+    for (int ks = 0; ks < NBK / 4; ++ks) {
+      double a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = As[(wr * 32 + mi * 16 + lr) * LDA_S + ks * 4 + lk];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) b[ni] = Rb[(size_t)(ks * 4 + lk) * npad + ni * 16 + lr];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+    lds_barrier();                                                 // As (the A operand) has been consumed
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          As[(wr * 32 + mi * 16 + lk + 4 * r) * LDA_S + wc * 32 + ni * 16 + lr] = acc[mi][ni][r];
+    lds_barrier();
+    constexpr int CPW = NBK / 4;                                   // 4 waves, 16 columns each, lane = row
+    double reg[CPW];
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) reg[j] = As[lane * LDA_S + wid * CPW + j];
+    gj_invert_regs<CPW>(reg, fcol, lane, wid);
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) Dinv_next[lane * NBK + wid * CPW + j] = reg[j];
+    return;
+  }
+  const int ib = (int)blockIdx.y - 1;
+  if (ib == kblk) return;
+  if ((int)(blockIdx.x * GJ_CT + GJ_CT - 1) < ib) return;        // the whole strip lies below the diagonal
   for (int e = tid; e < NBK * NBK; e += 256) {
     const int r = e >> 6, c = e & 63;
     As[r * LDA_S + c] = NZ[(size_t)(ib * NBK + r) * NBK + c];      // -Z_i
@@ -208,6 +272,7 @@ __global__ __launch_bounds__(256) void k_gj_trail_sym(double* __restrict__ A, in
   for (int t = 0; t < GJ_CT; ++t) {
     const int jb = blockIdx.x * GJ_CT + t;
     if (jb >= nblk || jb == kblk || jb < ib) continue;
+    if (ahead && ib == kn && jb == kn) continue;                   // the look-ahead workgroup owns the next pivot block
     double* Cb = A + (size_t)(ib * NBK + wr * 32) * npad + (size_t)jb * NBK + wc * 32;
     const double* Rb = XT + (size_t)jb * NBK + wc * 32;
     f64x4 acc[2][2];
@@ -472,6 +537,163 @@ __global__ __launch_bounds__(256) void k_prox_gemm(const float* __restrict__ Bm,
 }
 
 
+// ---- the same product on the bf16 matrix cores with both operands split in three --------------------------------
+// An fp32 value x is the exact sum of three bf16 values x1 + x2 + x3 (8 + 8 + 8 mantissa bits; bf16 has fp32's
+// exponent range, so no scaling is needed).  x y = sum_{i,j} x_i y_j; the six products with i + j <= 4 carry everything
+// down to 2^-24 of x y - the size of the rounding of an fp32 product itself - and each is EXACT in the fp32 accumulator
+// of v_mfma_f32_32x32x16_bf16 (8 x 8 bits).  Six bf16 MFMAs (32 x 32 x 16 each, 32 cycles) replace eight fp32 MFMAs
+// (32 x 32 x 2, 64 cycles) per K = 16: 0.375 of the matrix-core time for the same fp32-grade result.  The operands are
+// split ON THE FLY while a K tile is staged into LDS (3 planes of [rows][32 + 8] bf16, conflict-free b128 fragment
+// reads), so HBM / L2 still carry 4 bytes per element and nothing upstream changes.
+// Workgroup tile (128 MT_) x 256, 8 waves as WM_ x WN_; K tiles of 32; split K like k_prox_gemm.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int B3_K = 16;                       // K tile = one MFMA step
+constexpr int B3_LD = B3_K + 8;                // bf16 elements per LDS row (48 bytes: conflict-free b128 fragment reads)
+
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& p0, bf16x4& p1, bf16x4& p2) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 b0 = (__bf16)v[e];
+    const float r1 = v[e] - (float)b0;          // exact
+    const __bf16 b1 = (__bf16)r1;
+    const float r2 = r1 - (float)b1;            // exact
+    p0[e] = b0;
+    p1[e] = b1;
+    p2[e] = (__bf16)r2;
+  }
+}
+
+// Two LDS stages: while the MFMAs of K tile kt read stage kt & 1, the tile kt + 1 (fetched into registers one
+// iteration earlier) is split and stored into the other stage and the global loads of tile kt + 2 are issued - one
+// barrier per K tile, the conversion and the loads hide under the matrix-core work of the co-resident waves.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(512) void k_prox_gemm_b3(const float* __restrict__ Bm, int ldb, const float* __restrict__ Ainv,
+                                                      int lda, int n, int c2, int has_bias, float* __restrict__ wstar,
+                                                      float* __restrict__ bstar, float* __restrict__ part, int ldp) {
+  __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
+  constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+  constexpr int NA = BM * 4 / 512, NB = BN * 4 / 512;          // 16-byte global loads per thread per K tile
+  constexpr int STAGE = 3 * (BM + BN) * B3_LD;                  // bf16 elements per stage
+  static_assert(WM * WN == 8 && MT >= 1 && NT >= 1 && NA >= 1 && NB >= 1, "8 waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char b3_lds[];
+  __bf16* lds = reinterpret_cast<__bf16*>(b3_lds);              // [2][ As [3][BM][B3_LD] | Bs [3][BN][B3_LD] ]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+
+  f32x4 ra[NA], rb[NB];
+  const float* pa[NA];
+  const float* pb[NB];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int u = tid + q * 512, r = u >> 2, c4 = u & 3;
+    pa[q] = Bm + (size_t)(row0 + r) * ldb + c4 * 4;             // Bm is zero padded to the row tile
+  }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int u = tid + q * 512, r = u >> 2, c4 = u & 3;
+    pb[q] = Ainv + (size_t)min(col0 + r, n - 1) * lda + c4 * 4; // lda padded; columns >= n are dropped below
+  }
+#define EFFQ_B3_FETCH(k0)                                                           \
+  {                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < NA; ++q)                                  \
+        ra[q] = *reinterpret_cast<const f32x4*>(pa[q] + (k0));                      \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q)                                  \
+        rb[q] = *reinterpret_cast<const f32x4*>(pb[q] + (k0));                      \
+  }
+#define EFFQ_B3_STORE(stage)                                                                        \
+  {                                                                                                 \
+    __bf16* As_ = lds + (stage) * STAGE;                                                            \
+    __bf16* Bs_ = As_ + 3 * BM * B3_LD;                                                             \
+    _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                \
+      const int u = tid + q * 512, off = (u >> 2) * B3_LD + (u & 3) * 4;                            \
+      bf16x4 p0, p1, p2;                                                                            \
+      split3(ra[q], p0, p1, p2);                                                                    \
+      *reinterpret_cast<bf16x4*>(&As_[off]) = p0;                                                   \
+      *reinterpret_cast<bf16x4*>(&As_[BM * B3_LD + off]) = p1;                                      \
+      *reinterpret_cast<bf16x4*>(&As_[2 * BM * B3_LD + off]) = p2;                                  \
+    }                                                                                               \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                \
+      const int u = tid + q * 512, off = (u >> 2) * B3_LD + (u & 3) * 4;                            \
+      bf16x4 p0, p1, p2;                                                                            \
+      split3(rb[q], p0, p1, p2);                                                                    \
+      *reinterpret_cast<bf16x4*>(&Bs_[off]) = p0;                                                   \
+      *reinterpret_cast<bf16x4*>(&Bs_[BN * B3_LD + off]) = p1;                                      \
+      *reinterpret_cast<bf16x4*>(&Bs_[2 * BN * B3_LD + off]) = p2;                                  \
+    }                                                                                               \
+  }
+  const int nkt = ldb / B3_K;                   // ldb is a multiple of 32
+  const int kt0 = (int)(((long long)nkt * blockIdx.z) / gridDim.z);
+  const int nk = (int)(((long long)nkt * (blockIdx.z + 1)) / gridDim.z);
+  EFFQ_B3_FETCH(kt0 * B3_K)
+  EFFQ_B3_STORE(0)
+  EFFQ_B3_FETCH(min(kt0 + 1, nk - 1) * B3_K)
+  lds_barrier();
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int st = (kt - kt0) & 1;
+    if (kt + 1 < nk) EFFQ_B3_STORE(st ^ 1)       // tile kt + 1 (in registers since the previous iteration)
+    EFFQ_B3_FETCH(min(kt + 2, nk - 1) * B3_K)    // unconditional: past the end a harmless re-read
+    const __bf16* As = lds + st * STAGE;
+    const __bf16* Bs = As + 3 * BM * B3_LD;
+    bf16x8 a[MT][3], b[NT][3];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[m][p] = *reinterpret_cast<const bf16x8*>(&As[p * BM * B3_LD + ((wm * MT + m) * 32 + li) * B3_LD + 8 * lh]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        b[t][p] = *reinterpret_cast<const bf16x8*>(&Bs[p * BN * B3_LD + ((wn * NT + t) * 32 + li) * B3_LD + 8 * lh]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        // smallest terms first (x1 y3, x2 y2, x3 y1), then x1 y2, x2 y1, then x1 y1
+        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[t][2], acc[m][t], 0, 0, 0);
+        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[t][1], acc[m][t], 0, 0, 0);
+        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b[t][0], acc[m][t], 0, 0, 0);
+        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[t][1], acc[m][t], 0, 0, 0);
+        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[t][0], acc[m][t], 0, 0, 0);
+        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[t][0], acc[m][t], 0, 0, 0);
+      }
+    lds_barrier();                               // stage st has been read by every wave, stage st ^ 1 is complete
+  }
+#undef EFFQ_B3_FETCH
+#undef EFFQ_B3_STORE
+  const int nw = n - has_bias;
+  float* P = (gridDim.z > 1) ? part + (size_t)blockIdx.z * c2 * ldp : nullptr;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = col0 + (wn * NT + t) * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < c2 && col < n) {
+          if (P != nullptr)
+            P[(size_t)row * ldp + col] = acc[m][t][r];
+          else if (col < nw)
+            wstar[(size_t)row * nw + col] = acc[m][t][r];
+          else
+            bstar[row] = acc[m][t][r];
+        }
+      }
+    }
+}
+
 // What = sum_z part[z] in slice order (deterministic), scattered to [wstar | bstar]
 __global__ __launch_bounds__(256) void k_prox_reduce(const float* __restrict__ part, int ldp, int nsplit, int c2, int n,
                                                      int has_bias, float* __restrict__ wstar, float* __restrict__ bstar) {
@@ -499,6 +721,21 @@ static ProxPlan prox_plan(int c2, int n) {
   p.c2p = (c2 > 128) ? round_up(c2, 256) : (c2 > 64) ? 128 : round_up(c2, 32);
   p.ldb = round_up(n, 32);
   static const int wide = getenv("EFFQ_PROX_WIDE") ? atoi(getenv("EFFQ_PROX_WIDE")) : 0;   // tuning aid
+  // A/B switch of the bf16 x 3 kernel: bit 0 = rows > 128, bit 1 = the 128-row layers too (0 = f32 matrix cores)
+  static const int b3 = getenv("EFFQ_PROX_B3") ? atoi(getenv("EFFQ_PROX_B3")) : 3;
+  if (b3 && (p.c2p >= 256 || (p.c2p == 128 && (b3 & 2))) && n >= 1024) {
+    // 256 (128) x 256 tiles on the bf16 matrix cores (k_prox_gemm_b3), one workgroup of 8 waves per CU: K split so that
+    // the grid is about one round of the 256 CUs, at least 16 K tiles per slice
+    p.variant = (p.c2p >= 256) ? 5 : 6; p.gx = (n + 255) / 256; p.gy = (p.c2p >= 256) ? p.c2p / 256 : 1;
+    const int tiles5 = p.gx * p.gy, nkt5 = p.ldb / B3_K;
+    int s5 = (256 + tiles5 / 2) / tiles5;
+    if (s5 > nkt5 / 16) s5 = nkt5 / 16;
+    if (s5 < 1) s5 = 1;
+    static const int force5 = getenv("EFFQ_PROX_SPLIT") ? atoi(getenv("EFFQ_PROX_SPLIT")) : 0;   // tuning aid
+    if (force5 > 0 && force5 <= nkt5) s5 = force5;
+    p.nsplit = s5;
+    return p;
+  }
   if (p.c2p >= 256 && wide) { p.variant = 4; p.gx = (n + 127) / 128; p.gy = p.c2p / 256; }   // 256x128, waves 64x128
   else if (p.c2p >= 256) { p.variant = 0; p.gx = (n + 63) / 64; p.gy = p.c2p / 256; }        // 256x64, waves 64x64
   else if (p.c2p == 128) { p.variant = 1; p.gx = (n + 63) / 64; p.gy = 1; }             // 128x64, waves 32x64
@@ -535,7 +772,7 @@ extern "C" {
 size_t effq_spd_inverse_ws_bytes(int n) {
   if (n <= 0) return 0;
   const size_t npad = (size_t)round_up(n, NBK);
-  return npad * npad * sizeof(double) + 2 * (size_t)NBK * npad * sizeof(double) + NBK * NBK * sizeof(double) + 256;
+  return npad * npad * sizeof(double) + 2 * (size_t)NBK * npad * sizeof(double) + 2 * NBK * NBK * sizeof(double) + 256;
 }
 
 int effq_ainv_ld(int n) { return n > 0 ? round_up(n, 32) : 0; }
@@ -567,12 +804,18 @@ int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double et
     EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  // The trailing update of step k also forms the inverse of the NEXT pivot block (look-ahead workgroup, see
+  // k_gj_trail_sym): only step 0 needs the stand-alone k_gj_diag.  Dinv is double-buffered by step parity.
+  static const bool ahead_off = getenv("EFFQ_GJ_AHEAD") != nullptr && atoi(getenv("EFFQ_GJ_AHEAD")) == 0;   // A/B switch
   for (int k = 0; k < nblk; ++k) {
     const int kb = k * NBK;
-    hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(GJD_T), 0, st, A64, npad, kb, Dinv);
-    hipLaunchKernelGGL(k_gj_panel, dim3(nblk), dim3(256), lds, st, A64, npad, kb, Dinv, NZ, XT);
+    double* Dk = Dinv + (size_t)(k & 1) * NBK * NBK;
+    double* Dn = Dinv + (size_t)((k + 1) & 1) * NBK * NBK;
+    if (k == 0 || ahead_off) hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(GJD_T), 0, st, A64, npad, kb, Dk);
+    hipLaunchKernelGGL(k_gj_panel, dim3(nblk), dim3(256), lds, st, A64, npad, kb, Dk, NZ, XT);
     if (nblk > 1)
-      hipLaunchKernelGGL(k_gj_trail_sym, dim3((nblk + GJ_CT - 1) / GJ_CT, nblk), dim3(256), 0, st, A64, npad, kb, NZ, XT);
+      hipLaunchKernelGGL(k_gj_trail_sym, dim3((nblk + GJ_CT - 1) / GJ_CT, nblk + 1), dim3(256), 0, st, A64, npad, kb, NZ,
+                         XT, ahead_off ? (double*)nullptr : Dn);
     EFFQ_LAUNCH_CHECK();
   }
   {
@@ -627,6 +870,27 @@ static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, 
 #define EFFQ_PROX_LAUNCH(MT, WM, WN, NTN)                                                                              \
   hipLaunchKernelGGL((k_prox_gemm<MT, WM, WN, NTN>), grid, dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2, has_bias ? 1 : 0, \
                      wstar, bstar, part, ldb)
+    if (pl.variant == 5 || pl.variant == 6) {
+      const size_t lds5 = (size_t)2 * 3 * (256 + 256) * B3_LD * sizeof(__bf16);      // two stages
+      const size_t lds6 = (size_t)2 * 3 * (128 + 256) * B3_LD * sizeof(__bf16);
+      static bool attr5[64] = {};
+      int dev5 = 0;
+      EFFQ_HIP(hipGetDevice(&dev5));
+      EFFQ_CHECK_ARG(dev5 >= 0 && dev5 < 64);
+      if (!attr5[dev5]) {
+        EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prox_gemm_b3<256, 256, 4, 2>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
+        EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prox_gemm_b3<128, 256, 2, 4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6));
+        attr5[dev5] = true;
+      }
+      if (pl.variant == 5)
+        hipLaunchKernelGGL((k_prox_gemm_b3<256, 256, 4, 2>), grid, dim3(512), lds5, st, Bm, ldb, Ainv, lda, n, c2,
+                           has_bias ? 1 : 0, wstar, bstar, part, ldb);
+      else
+        hipLaunchKernelGGL((k_prox_gemm_b3<128, 256, 2, 4>), grid, dim3(512), lds6, st, Bm, ldb, Ainv, lda, n, c2,
+                           has_bias ? 1 : 0, wstar, bstar, part, ldb);
+    } else
     switch (pl.variant) {
       case 0: EFFQ_PROX_LAUNCH(2, 4, 1, 2); break;
       case 4: EFFQ_PROX_LAUNCH(2, 4, 1, 4); break;

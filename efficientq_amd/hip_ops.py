@@ -246,6 +246,11 @@ class HipOps:
         _, it, _ = self.fit_scale(v, levels, -1.0, 1.0, guess_iters=guess, state=state)
         return it
 
+    def fixed_point_sorted(self, a, b, v, levels: int, state, lo: float = -1.0, hi: float = 1.0):
+        """project_by_iter of v = a + b on sorted values, one launch (effq_fixed_point_sorted; <= 4096 values)."""
+        check(self.lib.effq_fixed_point_sorted(_ptr(a), _ptr(b), _ptr(v), a.numel(), levels, lo, hi, ADMM_TOL,
+                                               100 * levels, _ptr(state), self.stream), "effq_fixed_point_sorted")
+
     def fixed_point_bucket(self, a, b, v, levels: int, state, lo: float = -1.0, hi: float = 1.0):
         """project_by_iter of v = a + b (b may be None) on the bucketed copy: one workgroup, one launch
         (effq_fixed_point_bucket)."""
@@ -348,6 +353,22 @@ class HipOps:
                                               _ptr(Au), _ptr(Bu), _ptr(ws), ws.numel(), self.stream),
               "effq_gram_accum_i8_unw")
         return (A0, B0, Au, Bu) if unweighted else (A0, B0)
+
+    def gram_f64_supported(self, geom: Geom, has_bias: bool) -> bool:
+        return bool(self.lib.effq_gram_f64_supported(C.byref(geom), int(has_bias)))
+
+    def gram_f64(self, x_ndhwc: torch.Tensor, y_ndhwc: torch.Tensor, geom: Geom, has_bias: bool):
+        """(Au, Bu): the unweighted fp64 Gram system of a layer with full-precision input (effq_gram_f64) - the
+        operands of gram_loss() for the first conv and the classifier."""
+        x, y = self._f32(x_ndhwc), self._f32(y_ndhwc)
+        _check_shapes(geom, x, y=y)
+        n = geom.C1 * geom.KD * geom.KH * geom.KW + int(has_bias)
+        Au = torch.empty(n, n, dtype=torch.float64, device=self.device)
+        Bu = torch.empty(geom.C2, n, dtype=torch.float64, device=self.device)
+        ws = self._workspace("gram_f64", self.lib.effq_gram_f64_ws_bytes(C.byref(geom), int(has_bias)))
+        check(self.lib.effq_gram_f64(_ptr(x), _ptr(y), C.byref(geom), int(has_bias), _ptr(Au), _ptr(Bu), _ptr(ws),
+                                     ws.numel(), self.stream), "effq_gram_f64")
+        return Au, Bu
 
     def upsample_trilinear(self, x_ndhwc: torch.Tensor, scale) -> torch.Tensor:
         """nn.Upsample(scale_factor=scale, mode='trilinear') on an NDHWC tensor (effq_upsample_trilinear)."""
@@ -477,7 +498,11 @@ class HipOps:
         from types import SimpleNamespace
         c2, n = (int(i) for i in B0.shape)
         has_b = b0 is not None
-        W0 = self._f32(W0)
+        # convert ONCE and keep the converted tensors alive with the run (the call only enqueues work on three streams:
+        # a temporary .contiguous() copy could be handed back to the allocator while kernels still read it)
+        W0, A0, B0 = self._f32(W0), self._f32(A0), self._f32(B0)
+        b0 = self._f32(b0) if has_b else None
+        xq = self._f32(xq) if xq is not None else None
         nw = W0.numel()
         y = self._f32(y_ndhwc)
         if loss_gram is not None:
@@ -523,13 +548,13 @@ class HipOps:
         al = self._f32(act_alpha.reshape(1)) if (act_alpha is not None and loss_kind in (1, 2)) else None
         a = _lib.AdmmRunArgs()
         p = lambda t: None if t is None else t.data_ptr()
-        a.A0, a.B0, a.W0, a.b0 = p(self._f32(A0)), p(self._f32(B0)), p(W0), p(b0)
+        a.A0, a.B0, a.W0, a.b0 = p(A0), p(B0), p(W0), p(b0)
         a.c2, a.n, a.has_bias, a.w_levels = c2, n, int(has_b), int(levels)
         a.iters, a.rho_period = int(iters), int(period)
         a.rho, a.rho_max, a.eta, a.tol = float(rho), float(rho_max), float(eta), ADMM_TOL
         a.geom = geom
         a.loss_kind, a.act_levels = int(loss_kind), int(act_levels)
-        a.xq = p(self._f32(xq)) if loss_kind == 0 else None
+        a.xq = p(xq) if loss_kind == 0 else None
         a.xidx = p(xidx) if loss_kind in (1, 2) else None
         if loss_kind == 4:
             Au, Bu, syy = loss_gram

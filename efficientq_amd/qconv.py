@@ -358,6 +358,12 @@ class EfficientQConvHIP(PTQConv):
             A0, B0 = ops.gram_i8(xidx, att_cls, yn, geom, has_b, self.alpha_act.data, self.qlvl_act)
         else:
             A0, B0 = ops.gram(xq, att, yn, geom, has_b)
+            # full-precision input (first conv, classifier: quirk Q14): the same 200 losses from an fp64 Gram system
+            if (not self.q_act and GRAM_LOSS_DEFAULT and self.lwq_exact_int and n_sys <= GRAM_LOSS_MAX_N and
+                    yn.numel() // c2 >= 8 * n_sys and
+                    getattr(ops, "gram_f64_supported", lambda *a: False)(geom, has_b)):
+                Au, Bu = ops.gram_f64(xq, yn, geom, has_b)
+                loss_gram = (Au, Bu, syy_local)
         if red:                      # one message per layer: upper triangle of A0 + B0
             if hasattr(ops, "gram_reduce"):
                 ops.gram_reduce(A0, B0, red)

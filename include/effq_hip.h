@@ -108,14 +108,26 @@ int effq_alpha_fixed_point(const float* x, size_t n, int levels, double lo, doub
 size_t effq_fp_small_max(void);
 int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                            double tol, int max_iter, effq_fp_state* state_dev, void* stream);
+/* Same contract on SORTED values (n <= effq_fp_sorted_max() = 4096, levels <= 256): the values are sorted once with fp64
+ * prefix sums; one wave iterates with a lane per level boundary, re-finding each boundary's position from its previous
+ * one.  Level counts are exactly the reference's; meant for many-level quantisers (the 256-level weights of the first /
+ * last conv, ~300 iterations per call).  effq_fixed_point_small dispatches here when EFFQ_FP_SORTED=1. */
+size_t effq_fp_sorted_max(void);
+int effq_fixed_point_sorted(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                            double tol, int max_iter, effq_fp_state* state_dev, void* stream);
 /* Same contract for larger tensors (n <= effq_fp_coop_max()): one COOPERATIVE launch of ceil(n/27648) <= 256
  * workgroups (one per CU, slice of v resident in LDS) that meet at a bounded-spin grid barrier once per
  * iteration; partial sums are combined in workgroup order by every workgroup (deterministic).  state.done = 3
  * reports a barrier time-out.  ws: the reduction workspace (effq_reduce_ws_bytes()), zero-filled once by the caller:
- * the kernel keeps its barrier words in the tail of it and leaves them at zero. */
+ * the kernel keeps its barrier words in the tail of it and leaves them at zero.  A time-out POISONS the workspace: every
+ * later launch on it (e.g. the following ADMM iterations, already enqueued) returns at once with state.done = 3 and
+ * touches nothing, until the caller zero-fills the workspace again.
+ * effq_fp_coop_set_spin_limit: polls a workgroup waits at the barrier before it gives up (0 = the default, 2^24); a
+ * process-wide test hook - tests force the time-out path with a small value. */
 size_t effq_fp_coop_max(void);
 int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                           double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream);
+int effq_fp_coop_set_spin_limit(unsigned int polls);
 /* Same contract again (n <= effq_fp_bucket_max(), levels <= 256) without a per-iteration pass over the tensor: the
  * values are counted into equal-width buckets (exact integer sum per bucket) and regrouped by bucket once; each
  * iteration then reads prefix tables and looks only at the values of the bucket a level boundary falls into (those in
@@ -165,6 +177,17 @@ int effq_gram_accum_i8_unw(const uint8_t* xidx_ndhwc, const float* y_ndhwc, cons
                            const float* act_alpha_dev, int act_levels, const int32_t* vox_list, const int32_t* chunk_cls,
                            const float* cls_w_dev, int ncls, long long n_list, float* A0, float* B0, int accumulate,
                            double* Au, double* Bu, void* ws, size_t ws_bytes, void* stream);
+
+/* The unweighted system of a layer whose input is NOT quantised (first conv / classifier, q_first = q_last = "256,-1":
+ * definer.py:296-299, model_blk.py:98-107), in fp64 on the matrix cores: Au [n][n] = sum_v xhat xhat^T with
+ * xhat = [im2col patch of x (solver.py:86-111 row order); 1 if has_bias], Bu [c2][n] = sum_v y xhat^T.  fp32 inputs, exact
+ * products, fp64 accumulation, deterministic (partial slabs added in workgroup order).  Operands of effq_gram_loss for
+ * those layers.  Requires effq_gram_f64_supported (n = C1*KD*KH*KW + has_bias <= 128, C2 <= 64).
+ * ws: effq_gram_f64_ws_bytes(geom, has_bias). */
+int effq_gram_f64_supported(const effq_geom* g, int has_bias);
+size_t effq_gram_f64_ws_bytes(const effq_geom* g, int has_bias);
+int effq_gram_f64(const float* x_ndhwc, const float* y_ndhwc, const effq_geom* g, int has_bias, double* Au, double* Bu,
+                  void* ws, size_t ws_bytes, void* stream);
 
 /* ---- the loss of one iterate from the unweighted Gram system (EfficientQConv.py:118-122 without the pass over the voxels)
  * sum_v,c (conv(Qx, G, b)_v,c - y_v,c)^2 = sum_c g_c^T Au g_c - 2 sum_c g_c . Bu_c + syy with g_c = [G[c,:], b_c], in fp64:
@@ -246,7 +269,7 @@ int conv3d_quant_calib_step(const float* xq_ndhwc, const float* G, const float* 
  * activations and projected weights: x = alpha_a*k/(La-1) with level ids k (uint8, NDHWC) and
  * G = alpha_w*j'/(Lw-1) with Gq = j' (int8, reference weight layout).  The contraction runs on the i8
  * matrix cores with exact int32 accumulation; out = f32(alpha_a)*f32(alpha_w)/((La-1)(Lw-1)) * acc + bias.
- * Supported: 3x3x3, stride 1, C1 in {32,64,128,256}, C2 % 32 == 0, levels <= 128 (query effq_conv_i8_supported).
+ * Supported: 3x3x3, stride 1, C1 in {32,64,128,256,512}, C2 % 32 == 0, levels <= 128 (query effq_conv_i8_supported).
  * alpha_a: device float; alpha_w: w_state_dev->alpha.  sqerr_out[0] = sqerr_out[1] = sum (out-y)^2. */
 int effq_conv_i8_supported(const effq_geom* g, int act_levels, int w_levels);
 size_t effq_conv_i8_ws_bytes(const effq_geom* g);

@@ -10,7 +10,7 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for n, L in ((3456, 256), (6912, 256), (3456, 4), (8192, 4), (2048, 4), (16384, 4)):
+for n, L in ((3456, 256), (96, 256), (864, 256), (6912, 256), (3456, 64), (3456, 4), (8192, 4)):
     g = torch.Generator().manual_seed(n)
     W = (torch.randn(n, generator=g) * 0.05).to(dev); dual = torch.zeros_like(W); v = torch.empty_like(W)
     st = ops.new_fp_state()

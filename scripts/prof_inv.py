@@ -14,4 +14,4 @@ for n in ((865, 3457, 6913) if len(sys.argv) < 2 else tuple(int(v) for v in sys.
     for _ in range(3): ops.spd_inverse(A0, True, 30.0, 3.0, out=out)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 3
-    print(f"spd_inverse n={n}: {ms:.2f} ms  {2.0 * n ** 3 / ms / 1e9:.2f} TFLOP/s fp64 ({2.0 * n ** 3 / ms / 1e9 / 78.6 * 100:.1f}% of f64 MFMA peak)")
+    print(f"spd_inverse n={n}: {ms:.2f} ms  {1.0 * n ** 3 / ms / 1e9:.2f} TFLOP/s fp64, n^3 flop: symmetric sweep ({1.0 * n ** 3 / ms / 1e9 / 78.6 * 100:.1f}% of f64 MFMA peak)")

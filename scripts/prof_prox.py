@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from efficientq_amd.hip_ops import get_ops
 dev = "cuda:0"; ops = get_ops(dev)
-for c2, n in ((32, 865), (64, 1729), (128, 3457), (256, 6913)):
+for c2, n in ((32, 865), (64, 1729), (128, 3457), (256, 6913)) + (((512, 13825),) if os.environ.get('PROX_LITS') else ()):
     g = torch.Generator().manual_seed(n)
     lda = ops.lib.effq_ainv_ld(n)
     Ainv = torch.zeros(n, lda, device=dev); Ainv[:, :n] = torch.randn(n, n, generator=g).to(dev) * 1e-3

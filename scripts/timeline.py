@@ -71,6 +71,24 @@ def main():
           f"({100 * (span - busy) / span:.1f} %)")
     for (q, st), ms in sorted(per_q.items(), key=lambda kv: -kv[1]):
         print(f"  queue {q} stream {st}: {ms:.1f} ms of kernels")
+    # the same per queue: where does the busiest queue (the ADMM chain) wait?  (a wait for another stream's event or for
+    # the host shows up as a gap on this queue while the device is busy elsewhere)
+    main_q = max(per_q.items(), key=lambda kv: kv[1])[0]
+    qrows = [r for r in rows if (r[3], r[4]) == main_q]
+    qgaps = defaultdict(lambda: [0, 0.0])
+    qidle = 0.0
+    for (s0, e0, n0, *_a), (s1, e1, n1, *_b) in zip(qrows, qrows[1:]):
+        g = (s1 - e0) / 1e3
+        if g > 0:
+            qidle += g
+        if g >= min_gap:
+            k = (short(n0), short(n1))
+            qgaps[k][0] += 1
+            qgaps[k][1] += g
+    print(f"busiest queue {main_q}: {len(qrows)} kernels, idle between its kernels {qidle / 1e3:.1f} ms; gaps >= "
+          f"{min_gap:.0f} us: {sum(v[1] for v in qgaps.values()) / 1e3:.1f} ms")
+    for (a, b), (n, us) in sorted(qgaps.items(), key=lambda kv: -kv[1][1])[:top]:
+        print(f"  [main] {us / 1e3:8.2f} ms {n:5d} x {us / n:8.1f} us   {a}  ->  {b}")
     tot = sum(v[1] for v in gaps.values()) / 1e3
     print(f"idle gaps >= {min_gap:.0f} us: {tot:.1f} ms in {sum(v[0] for v in gaps.values())} gaps")
     for (a, b), (n, us) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:top]:

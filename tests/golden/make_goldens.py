@@ -7,7 +7,9 @@ Run only in the build container (``/root/reference`` present):
 The reference is imported read-only (``sys.dont_write_bytecode``); its one
 missing dependency on the orchestrator path, ``nibabel``, is replaced by a
 no-op stand-in module.  Only inputs and outputs (data)
-are written; no reference source travels.  Fixtures: G1..G10 of SURVEY.md 8(c), G11 for row f1.
+are written; no reference source travels.  Fixtures: G1..G10 of SURVEY.md 8(c), G11 for row f1, G12 for row f3,
+g5b / g5d (wide layers: reference self-spread and the fp64 anchor), g6c / g6d (GPU hook behaviour; wide whole nets).
+With no arguments EVERY fixture is regenerated.
 """
 import argparse
 import os
@@ -159,10 +161,14 @@ def g3_g4():
 
 
 # ---------------------------------------------------------------- G5 one layer ptq
-def run_layer(c1, c2, k, stride, pad, N, S, L_w, L_a, q_act, seed, with_mask, bias=True):
+def run_layer(c1, c2, k, stride, pad, N, S, L_w, L_a, q_act, seed, with_mask, bias=True, iters=None):
+    """iters: run only the first `iters` ADMM iterations (lwq_iter is an instance attribute, EfficientQConv.py:23);
+    the loss history then has `iters` entries and rec["wstar0"/"bstar0"] hold the FIRST proximal solve."""
     gen = torch.Generator().manual_seed(seed)
     conv = models.EfficientQConv(c1, c2, k, stride, pad, 1, 1, bias, q_weight=True, qlvl=L_w,
                                  q_act=q_act, qlvl_act=L_a)
+    if iters is not None:
+        conv.lwq_iter = int(iters)
     with torch.no_grad():
         conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (1.0 / (c1 * k ** 3) ** 0.5))
         if bias:
@@ -189,20 +195,36 @@ def run_layer(c1, c2, k, stride, pad, N, S, L_w, L_a, q_act, seed, with_mask, bi
         losses.append(r.item())
         return r
 
+    first_proj = []
+
     def proj_spy(v, L, lo=-1., hi=1.):
         a, b = orig_proj(v, L, lo, hi)
         alphas.append((lo, a))
+        if lo < 0 and not first_proj:
+            first_proj.append(torch.round((b.detach() - lo) / ((hi - lo) / (L - 1))).to(torch.uint8))
         return a, b
 
+    first_solve = []
+    orig_solve = solver.QuadraSolver.solve
+
+    def solve_spy(self_, *a, **kw):
+        r = orig_solve(self_, *a, **kw)
+        if not first_solve:
+            first_solve.append(tuple(t.detach().clone() for t in r) if isinstance(r, tuple) else (r.detach().clone(),))
+        return r
+
     F.mse_loss, EQ_MOD.project_by_iter = mse_spy, proj_spy
+    solver.QuadraSolver.solve = solve_spy
     try:
         with torch.no_grad():
             conv.ptq(x)
     finally:
         F.mse_loss, EQ_MOD.project_by_iter = orig_mse, orig_proj
+        solver.QuadraSolver.solve = orig_solve
+    n_it = conv.lwq_iter
     aw_hist = np.array([a for lo, a in alphas if lo < 0], dtype=np.float64)
-    rec = dict(x=x, y=y, w_in=w_in, loss_hist=np.array(losses[:200], dtype=np.float64),
-               final_mse=np.float64(losses[200]), aw_hist=aw_hist,
+    rec = dict(x=x, y=y, w_in=w_in, loss_hist=np.array(losses[:n_it], dtype=np.float64),
+               final_mse=np.float64(losses[n_it]), aw_hist=aw_hist, wstar0=first_solve[0][0], G0idx=first_proj[0],
                weight=conv.weight.data, alpha_w=conv.alpha_w.data, alpha_act=conv.alpha_act.data,
                layer_loss=np.float64(float(conv.layer_loss[0].split(":")[1])),
                meta=np.array([c1, c2, k, pad, N, S, L_w, L_a, int(q_act), int(with_mask)]),
@@ -210,6 +232,7 @@ def run_layer(c1, c2, k, stride, pad, N, S, L_w, L_a, q_act, seed, with_mask, bi
     if bias:
         rec["b_in"] = b_in
         rec["bias"] = conv.bias.data
+        rec["bstar0"] = first_solve[0][1]
     if with_mask:
         rec["mask_full"] = m_full
     # the forward that feeds the next layer (PTQConv.py:157-162)
@@ -231,6 +254,7 @@ def g5():
                    with_mask=False),
     }.items():
         rec = run_layer(**kw)
+        rec.pop("wstar0", None), rec.pop("bstar0", None), rec.pop("G0idx", None)   # (kept out of this fixture: see g5d)
         for k, v in rec.items():
             out[f"{tag}_{k}"] = v
         print(tag, "layer_loss", rec["layer_loss"], "best", int(np.argmin(rec["loss_hist"])))
@@ -243,18 +267,14 @@ def g5b():
     inside the library GEMM / conv kernels; whatever distance separates them is the reference's own reproducibility
     floor for this layer shape, and the bar of the product tests is anchored on it."""
     out = {}
-    for tag, kw in {
-        "c32": dict(c1=32, c2=32, k=3, stride=1, pad=1, N=2, S=12, L_w=4, L_a=4, q_act=True, seed=2024,
-                    with_mask=True),
-        # (V = 2 * 12^3 = 3456 output voxels for n = 1729 unknowns: an over-determined system like the real layers)
-        "c64": dict(c1=64, c2=64, k=3, stride=1, pad=1, N=2, S=12, L_w=4, L_a=4, q_act=True, seed=2025,
-                    with_mask=True),
-    }.items():
+    # (c64: V = 2 * 12^3 = 3456 output voxels for n = 1729 unknowns: an over-determined system like the real layers)
+    for tag, kw in G5B_CASES.items():
         sub = 2 if tag == "c64" else 1          # fwd_q is kept on every sub-th voxel per axis (fixture size)
         recs = {}
         for nt in (1, 8):
             torch.set_num_threads(nt)
             recs[nt] = run_layer(**kw)
+            recs[nt].pop("wstar0", None), recs[nt].pop("bstar0", None), recs[nt].pop("G0idx", None)
         torch.set_num_threads(8)
         base = recs[8]
         for k in ("x", "y", "w_in", "b_in", "mask_full", "meta", "stride"):
@@ -282,6 +302,76 @@ def g5b():
         print(tag, {k: f"{v:.3e}" for k, v in spread.items()}, "layer_loss t1/t8", a["layer_loss"], b["layer_loss"],
               "best it", int(np.argmin(a["loss_hist"])), int(np.argmin(b["loss_hist"])))
     save("g5b_wide_layers.npz", **out)
+
+
+G5B_CASES = {
+    "c32": dict(c1=32, c2=32, k=3, stride=1, pad=1, N=2, S=12, L_w=4, L_a=4, q_act=True, seed=2024, with_mask=True),
+    "c64": dict(c1=64, c2=64, k=3, stride=1, pad=1, N=2, S=12, L_w=4, L_a=4, q_act=True, seed=2025, with_mask=True),
+}
+
+
+def g5d():
+    """fp64 ANCHOR for the wide layers of g5b.  For the same 32->32 / 64->64 layers:
+      * the reference's FIRST proximal solve w*_0, b*_0 and its first 8 losses, with 1 and with 8 BLAS threads
+        (lwq_iter = 8: the prefix of the 200-iteration runs of g5b, checked against them);
+      * the oracle's fp64 evaluation of the same arithmetic (oracle.calibrate_layer(dtype=float64), whose fp32 mode
+        reproduces the reference bit for bit): w*_0, b*_0, the whole loss history, final weight levels, layer_loss.
+    The product test asserts that the HIP path is no farther from the fp64 values than the reference's own runs."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import effq_oracle as O
+    g5b_file = np.load(os.path.join(HERE, "g5b_wide_layers.npz"))
+    out = {}
+    for tag, kw in G5B_CASES.items():
+        recs = {}
+        for nt in (1, 8):
+            torch.set_num_threads(nt)
+            recs[nt] = run_layer(iters=8, **kw)
+            assert np.array_equal(recs[nt]["loss_hist"], g5b_file[f"{tag}_t{nt}_loss_hist"][:8]), "prefix of the g5b run"
+        torch.set_num_threads(8)
+        base = recs[8]
+        assert np.array_equal(base["x"].numpy(), g5b_file[f"{tag}_x"])
+        N = base["x"].shape[0]
+        pyr = [torch.ones(N, *[d // 2 for d in base["y"].shape[2:]]), base["mask_full"]]
+        # the switch off reproduces the reference (fp32) ...
+        chk = O.calibrate_layer(base["x"], base["y"], base["w_in"], base["b_in"], 1, 1, qlvl_w=kw["L_w"],
+                                qlvl_act=kw["L_a"], mask_pyramid=pyr, iters=8)
+        assert np.array_equal(np.array(chk.loss_history), base["loss_hist"]), "oracle fp32 == reference"
+        assert torch.equal(chk.wstar0, base["wstar0"])
+        # ... and switched on it is the anchor
+        r = O.calibrate_layer(base["x"], base["y"], base["w_in"], base["b_in"], 1, 1, qlvl_w=kw["L_w"],
+                              qlvl_act=kw["L_a"], mask_pyramid=pyr, dtype=torch.float64)
+        L = kw["L_w"]
+        idx = torch.round((r.weight / r.weight.abs().max() + 1) * (L - 1) / 2).to(torch.uint8)
+        out[f"{tag}_f64_loss_hist"] = np.array(r.loss_history, dtype=np.float64)
+        out[f"{tag}_f64_wstar0"] = r.wstar0.float()          # (fp32 storage: 6e-8 relative, the distances are >= 1e-6)
+        out[f"{tag}_f64_bstar0"] = r.bstar0
+        out[f"{tag}_f64_weight_idx"] = idx
+        # iteration 0 in fp64: v_0 = w*_0 (dual = 0), its scale and level ids, and each weight's distance (in level
+        # units) from the nearest rounding boundary - a run may differ from fp64 at iteration 0 only where that is tiny
+        fit0 = O.fit_scale(r.wstar0, L, -1.0, 1.0)
+        dl_ = 2.0 / (L - 1)
+        u0 = (torch.clamp(r.wstar0 / fit0.alpha, -1.0, 1.0) + 1.0) / dl_
+        out[f"{tag}_f64_aw0"] = np.float64(fit0.alpha)
+        out[f"{tag}_f64_G0idx"] = torch.round(u0).to(torch.uint8)
+        out[f"{tag}_f64_margin0"] = (u0 - torch.floor(u0) - 0.5).abs().float()
+        out[f"{tag}_f64_layer_loss"] = np.float64(r.layer_loss)
+        out[f"{tag}_f64_alpha_act"] = np.float64(r.alpha_act)
+        for nt, rec in recs.items():
+            out[f"{tag}_t{nt}_wstar0"] = rec["wstar0"]
+            out[f"{tag}_t{nt}_bstar0"] = rec["bstar0"]
+            out[f"{tag}_t{nt}_loss8"] = rec["loss_hist"]
+            out[f"{tag}_t{nt}_G0idx"] = rec["G0idx"]
+            out[f"{tag}_t{nt}_aw0"] = np.float64(rec["aw_hist"][0])
+            mm = rec["G0idx"] != out[f"{tag}_f64_G0idx"]
+            print(tag, f"t{nt}: iteration-0 level ids differ from fp64 at {int(mm.sum())} of {mm.numel()} weights, "
+                  f"largest boundary margin among them {float(out[f'{tag}_f64_margin0'][mm].max()) if mm.any() else 0:.2e}")
+        w64 = r.wstar0
+        d = {nt: ((recs[nt]["wstar0"].double() - w64).norm() / w64.norm()).item() for nt in (1, 8)}
+        dl = {nt: np.abs(recs[nt]["loss_hist"][:5] - np.array(r.loss_history[:5])) / np.array(r.loss_history[:5])
+              for nt in (1, 8)}
+        print(tag, "w*0 rel distance to fp64: t1 %.3e t8 %.3e" % (d[1], d[8]), "loss[0:5] rel distance t1", dl[1],
+              "t8", dl[8], "fp64 layer_loss", r.layer_loss, "best it", r.best_iter)
+    save("g5d_wide_fp64_anchor.npz", **out)
 
 
 # ---------------------------------------------------------------- G6 whole do_ptq
@@ -321,20 +411,23 @@ def _copying_hook(m, i, o):
     m.output_fp = o.detach().clone()
 
 
-def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_targets=False):
+def run_do_ptq(task, L, S, width="8,16,8", copy_targets=False, threads=8, seed=606):
+    """The reference's real do_ptq (ptqer.py:282-387) on a seeded random network and seeded volumes; returns what it
+    produced.  copy_targets: hooks.py:5-6 as it behaves on a GPU (see _copying_hook)."""
     root = "/tmp/effq_gold"
+    torch.set_num_threads(threads)
     orig_hook = ptqer.forward_hook
     if copy_targets:
         ptqer.forward_hook = _copying_hook
     os.makedirs(root + "/snap", exist_ok=True)
     if task == "lits":
-        args = tiny_args("lits", L, S, 1, 3)
+        args = tiny_args("lits", L, S, 1, 3, width=width)
     else:
-        args = tiny_args("brats", L, S, 2, 4, multi_label="brats", init_stride="2,2,2")
+        args = tiny_args("brats", L, S, 2, 4, multi_label="brats", init_stride="2,2,2", width=width)
     QConv, Qinfo, kwQ = definer.get_conv_class(args)
     mc, _ = definer.get_model_cube(args, QConv, kwQ)
     model = mc["model"]
-    randomise(model, 606)
+    randomise(model, seed)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     torch.save({"state_dict": model.state_dict()}, args.pretrain)
     nmod = args.nMod
@@ -383,10 +476,19 @@ def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_tar
     finally:
         ptqer.set_mask, ptqer.extract_nii = orig_set_mask, orig_extract
         ptqer.forward_hook = orig_hook
+        torch.set_num_threads(8)
     with open(root + "/snap/layer_loss.txt") as f:
         ll = f.read().strip().split("\n")
     with open(root + "/snap/class_voxel_nums.txt") as f:
         nums = [int(float(t)) for t in f.read().split()]
+    with open(root + "/snap/time_cost.txt") as f:
+        print("reference time_cost:", f.read())
+    return dict(ll=ll, nums=nums, outs=outs, captured=captured, sd0=sd0, vols=vols, L=L, S=S)
+
+
+def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_targets=False):
+    r = run_do_ptq(task, L, S, copy_targets=copy_targets)
+    ll, nums, outs, captured, sd0, vols = r["ll"], r["nums"], r["outs"], r["captured"], r["sd0"], r["vols"]
     sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4), slice(None, None, 4))
     out = {"vols_seed": np.int64(1), "vols_check": vols[:, :, ::8, ::8, ::8],
            "output_q_sub": outs[0][-1][sub], "output_fp_sub": outs[1][-1][sub],
@@ -397,8 +499,6 @@ def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_tar
            "layer_loss": np.array([float(l.split(":")[1]) for l in ll], dtype=np.float64),
            "class_nums": np.array(nums, dtype=np.int64),
            "meta": np.array([L, S])}
-    with open(root + "/snap/time_cost.txt") as f:
-        print("reference time_cost:", f.read())
     for i, p in enumerate(captured["pyr"]):
         out[f"pyr{i}"] = p.to(torch.uint8)
         assert (p == p.to(torch.uint8).float()).all()
@@ -411,6 +511,59 @@ def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_tar
             out["sdi/" + k] = v
     save(tag + ".npz", **out)
     print("\n".join(ll))
+
+
+def g6d(tasks=("lits", "brats")):
+    """Whole-network goldens at the widths that matter: the reference's real do_ptq on a
+    width 32,64,32 net (n = 865 / 1729 systems), LiTS 2 x 1x32^3 and BraTS 2 x 2x64^3 with zero background, 4/4 levels.
+    Per task: the GPU hook behaviour (targets copied, _copying_hook) and the CPU hook behaviour (targets aliased), each
+    with 8 and with 1 BLAS thread - the second run is the reference's own reproducibility floor per layer and for the
+    FP-vs-Q agreement.  The start weights are NOT stored: they are `randomise(model, 606)`, which the
+    product's synth.randomise_network reproduces (a checksum per tensor is stored instead)."""
+    for task, S in (("lits", 32), ("brats", 64)):
+        if task not in tasks:
+            continue
+        runs = {"copy_t8": run_do_ptq(task, 4, S, "32,64,32", True, 8),
+                "copy_t1": run_do_ptq(task, 4, S, "32,64,32", True, 1),
+                "alias_t8": run_do_ptq(task, 4, S, "32,64,32", False, 8),
+                "alias_t1": run_do_ptq(task, 4, S, "32,64,32", False, 1)}
+        base = runs["copy_t8"]
+        out = {"meta": np.array([4, S]), "vols_seed": np.int64(1), "net_seed": np.int64(606),
+               "vols_check": base["vols"][:, :, ::8, ::8, ::8],
+               "layer_names": np.array([l.split(":")[0].strip() for l in base["ll"]]),
+               "class_nums": np.array(base["nums"], dtype=np.int64)}
+        for k, v in base["sd0"].items():
+            if v.dtype.is_floating_point:
+                out["sd0sum/" + k] = np.float64(v.double().sum().item())
+        for i, p in enumerate(base["captured"]["pyr"]):
+            out[f"pyr{i}"] = p.to(torch.uint8)
+            assert (p == p.to(torch.uint8).float()).all()
+        sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4), slice(None, None, 4))
+        for tag, r in runs.items():
+            oq, of = r["outs"][0][-1], r["outs"][1][-1]
+            out[f"{tag}/layer_loss"] = np.array([float(l.split(":")[1]) for l in r["ll"]], dtype=np.float64)
+            out[f"{tag}/agree"] = np.float64(((oq > 0) == (of > 0)).float().mean().item())
+            out[f"{tag}/output_q_sub"] = oq[sub]
+            out[f"{tag}/out_rel_mse_vs_fp"] = np.float64((((oq - of) ** 2).mean() / (of ** 2).mean()).item())
+            assert r["nums"] == base["nums"]
+            sdq = r["captured"]["state_in_fp.pkl"]
+            sdi = r["captured"]["state_in_int8.pkl"]
+            for k, v in sdq.items():
+                if k.endswith("alpha_w") or k.endswith("alpha_act"):
+                    out[f"{tag}/sdq/{k}"] = v
+                elif k.endswith(".bias") and k[:-5] + ".alpha_w" in sdq:
+                    out[f"{tag}/sdq/{k}"] = v
+            if tag == "copy_t8":
+                out["output_fp_sub"] = of[sub]
+            for k, v in sdi.items():
+                if k.endswith(".weight") and v.dtype == torch.uint8 and tag == "copy_t8":
+                    out[f"{tag}/sdi/{k}"] = v
+        a, b = runs["copy_t1"], runs["copy_t8"]
+        la = np.array([float(l.split(":")[1]) for l in a["ll"]])
+        lb = np.array([float(l.split(":")[1]) for l in b["ll"]])
+        print(task, "self-spread of layer_loss (t1 vs t8):", np.abs(la - lb) / lb)
+        print(task, "agree copy t8/t1/alias:", out["copy_t8/agree"], out["copy_t1/agree"], out["alias_t8/agree"])
+        save(f"g6d_wide_{task}_L4.npz", **out)
 
 
 # ---------------------------------------------------------------- G7 BN fold
@@ -528,35 +681,6 @@ def g11():
     save("g11_sliding_window.npz", **out)
 
 
-if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3g4", "g5", "g6", "g6b", "g7", "g8", "g9", "g10", "g11"]
-    with torch.no_grad():
-        if "g1" in which:
-            g1()
-        if "g2" in which:
-            g2()
-        if "g3g4" in which:
-            g3_g4()
-        if "g7" in which:
-            g7()
-        if "g8" in which:
-            g8()
-        if "g9" in which:
-            g9()
-        if "g10" in which:
-            g10()
-        if "g11" in which:
-            g11()
-    if "g5" in which:
-        g5()
-    if "g5b" in which:
-        g5b()
-    if "g6" in which:
-        g6("lits", 4, 32, "g6_tiny_lits_L4")
-    if "g6b" in which:
-        g6("brats", 4, 64, "g6_tiny_brats_L4")
-
-
 # ---------------------------------------------------------------- G12 tune_activation_range (row f3)
 def g12():
     """The reference's tune_activation_range (ptqer.py:238-272; dead code there, run in isolation here) on the tiny
@@ -600,8 +724,32 @@ def g12():
     save("g12_tune_act.npz", **out)
 
 
-if __name__ == "__main__" and "g12" in sys.argv[1:]:
-    g12()
-if __name__ == "__main__" and "g6c" in sys.argv[1:]:
-    g6("lits", 4, 32, "g6c_tiny_lits_L4", copy_targets=True)
-    g6("brats", 4, 64, "g6c_tiny_brats_L4", copy_targets=True)
+if __name__ == "__main__":
+    ALL = ["g1", "g2", "g3g4", "g5", "g5b", "g5d", "g6", "g6b", "g6c", "g6d", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ALL
+    with torch.no_grad():
+        for name, fn in (("g1", g1), ("g2", g2), ("g3g4", g3_g4), ("g7", g7), ("g8", g8), ("g9", g9), ("g10", g10),
+                         ("g11", g11)):
+            if name in which:
+                fn()
+    if "g5" in which:
+        g5()
+    if "g5b" in which:
+        g5b()
+    if "g5d" in which:
+        g5d()                      # (reads g5b_wide_layers.npz: after g5b)
+    if "g6" in which:
+        g6("lits", 4, 32, "g6_tiny_lits_L4")
+    if "g6b" in which:
+        g6("brats", 4, 64, "g6_tiny_brats_L4")
+    if "g6c" in which:
+        g6("lits", 4, 32, "g6c_tiny_lits_L4", copy_targets=True)
+        g6("brats", 4, 64, "g6c_tiny_brats_L4", copy_targets=True)
+    if "g6d" in which:
+        g6d()
+    if "g6d_lits" in which:
+        g6d(("lits",))
+    if "g6d_brats" in which:
+        g6d(("brats",))
+    if "g12" in which:
+        g12()

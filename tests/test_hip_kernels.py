@@ -272,6 +272,38 @@ def test_spd_inverse_and_prox(ops, n, c2):
     assert (got0 - want0).abs().max() <= 3e-5 * want0.abs().max()
 
 
+@pytest.mark.parametrize("n,c2", [(1025, 256), (1301, 200), (2081, 512), (3457, 128), (865, 32)])
+def test_prox_product_is_fp32_grade_on_every_kernel_variant(ops, n, c2):
+    """What = Bm * Ainv of the prox solve against the fp64 product of the SAME fp32 operands.  For c2 > 128 and
+    n >= 1024 the product runs on the bf16 matrix cores with both operands split in three (k_prox_gemm_b3: six exact
+    bf16 products per fp32 product, terms below 2^-24 dropped); the smaller shapes on the f32 matrix cores.  Both must
+    be fp32-grade: error <= 4e-7 of |Bm| |Ainv| accumulated over K (an fp32 dot product of length n in random order sits
+    at ~1e-7 sqrt(n) / n of that bound) - and row / column remainders, the bias column and the K split must be right."""
+    gen = torch.Generator().manual_seed(n + c2)
+    lda = ops.lib.effq_ainv_ld(n)
+    S = torch.randn(n, n, generator=gen) * 1e-3
+    S = 0.5 * (S + S.T)                                            # the kernels use the symmetry of A^-1
+    Ainv = torch.zeros(n, lda)
+    Ainv[:, :n] = S
+    B0 = torch.randn(c2, n, generator=gen) * 10
+    W0 = torch.randn(c2, n - 1, generator=gen)
+    b0 = torch.randn(c2, generator=gen)
+    G = torch.randn(c2, n - 1, generator=gen)
+    dual = torch.randn(c2, n - 1, generator=gen) * 0.1
+    rho, eta = 30.0, 3.0
+    wstar = torch.empty(c2, n - 1, device="cuda:0")
+    bstar = torch.empty(c2, device="cuda:0")
+    ops.prox_solve(dev(B0), dev(Ainv), dev(W0), dev(b0), dev(G), dev(dual), rho, eta, wstar, bstar)
+    # Bm exactly as the build kernel forms it in fp32 (solver.py:316-322 op order)
+    Bm = torch.cat([(B0[:, :-1] + np.float32(eta) * W0) + np.float32(rho) * (G - dual),
+                    (B0[:, -1] + np.float32(eta) * b0)[:, None]], 1)
+    want = Bm.double() @ S.double()
+    bound = Bm.double().abs() @ S.double().abs()
+    got = torch.cat([wstar.cpu(), bstar.cpu()[:, None]], 1).double()
+    assert ((got - want).abs() <= 4e-7 * bound).all(), ((got - want).abs() / bound).max()
+    assert (got - want).abs().max() <= 2e-6 * want.abs().max()
+
+
 # ------------------------------------------------------------------ the conv entry point
 CONV_CASES = [
     # c1, c2, k, stride, pad, spatial
@@ -494,6 +526,52 @@ def test_loss_from_the_unweighted_gram_system_equals_the_conv_loss(ops, c1, c2, 
     _, sq32 = ops.conv_step(xq, G, b, geom, y, None)
     assert abs(sq32.cpu().tolist()[0] - got[0]) <= 2e-6 * ref
     assert ops.gram_loss(Au, Bu, syy, G, b).cpu().tolist() == got          # deterministic
+
+
+@pytest.mark.parametrize("c1,c2,k,s,pad,sp,with_bias", [
+    (4, 32, 3, 2, 1, (16, 14, 18), True),          # BraTS first conv (n = 109), ragged voxel count
+    (32, 3, 1, 1, 0, (9, 7, 11), True),            # classifier (n = 33, c2 = 3)
+    (1, 32, 3, (2, 2, 1), 1, (12, 10, 9), True),   # LiTS first conv, stride 2,2,1 (n = 28)
+    (4, 8, 3, 1, 1, (5, 6, 7), False),             # no bias (n = 108)
+    (2, 64, 3, 1, 0, (6, 6, 6), True)])            # no padding, c2 = 64
+def test_fp64_gram_system_of_a_full_precision_input(ops, c1, c2, k, s, pad, sp, with_bias):
+    """effq_gram_f64: Au = sum xhat xhat^T, Bu = sum y xhat^T in fp64 (products of fp32 values are exact, the sums differ
+    from numpy's by rounding order only: <= 1e-13 of the largest entry), reference im2col row order, deterministic; and the
+    loss effq_gram_loss forms from it equals the fp64 conv loss <= 1e-10 and the conv entry point's <= 2e-6."""
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(c1 * 11 + c2 + k)
+    N = 2
+    x = torch.randn(N, *sp, c1, generator=gen)
+    geom = make_geom((N, c1, *sp), c2, k, s, pad)
+    assert ops.gram_f64_supported(geom, with_bias)
+    od, oh, ow = geom.out_dims()
+    y = torch.randn(N, od, oh, ow, c2, generator=gen)
+    Au, Bu = ops.gram_f64(dev(x), dev(y), geom, with_bias)
+    X = O.patch_matrix(x.permute(0, 4, 1, 2, 3).numpy(), (k, k, k), s, pad, ones_row=with_bias,
+                       dtype=np.float64)
+    Y = y.double().reshape(-1, c2).numpy().T
+    assert Au.shape == (X.shape[0], X.shape[0]) and Bu.shape == (c2, X.shape[0])
+    assert np.abs(Au.cpu().numpy() - X @ X.T).max() <= 1e-13 * np.abs(X @ X.T).max()
+    assert np.abs(Bu.cpu().numpy() - Y @ X.T).max() <= 1e-13 * max(np.abs(Y @ X.T).max(), 1.0)
+    assert torch.equal(Au, Au.T)
+    Au2, Bu2 = ops.gram_f64(dev(x), dev(y), geom, with_bias)
+    assert torch.equal(Au, Au2) and torch.equal(Bu, Bu2)                       # deterministic
+    G = dev(torch.randn(c2, c1, k, k, k, generator=gen) * 0.1)
+    b = dev(torch.randn(c2, generator=gen) * 0.1) if with_bias else None
+    syy = (dev(y).double() ** 2).sum().reshape(1)
+    got = ops.gram_loss(Au, Bu, syy, G, b).cpu().tolist()
+    out = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).double(), G.cpu().double(),
+                                     None if b is None else b.cpu().double(), s, pad)
+    ref = ((out - y.permute(0, 4, 1, 2, 3).double()) ** 2).sum().item()
+    assert abs(got[0] - ref) <= 1e-10 * ref, (got, ref)
+    _, sq32 = ops.conv_step(dev(x), G, b, geom, dev(y), None)
+    assert abs(sq32.cpu().tolist()[0] - got[0]) <= 2e-6 * ref
+
+
+def test_fp64_gram_system_rejects_what_it_cannot_do(ops):
+    from efficientq_amd.hip_ops import make_geom
+    assert not ops.gram_f64_supported(make_geom((1, 32, 8, 8, 8), 32, 3, 1, 1), True)      # n = 865 > 128
+    assert not ops.gram_f64_supported(make_geom((1, 4, 8, 8, 8), 128, 1, 1, 0), True)      # c2 > 64
 
 
 @pytest.mark.parametrize("sp,La,Lw,with_bias", [((16, 8, 8), 4, 4, True), ((5, 6, 9), 4, 4, True), ((17, 4, 8), 16, 16, False),
@@ -771,6 +849,70 @@ def test_bucketed_fixed_point_on_adversarial_values(ops, L):
         except RuntimeWarning:
             fit = None
         (alpha, iters, done), _ = _run_bucket(ops, x.contiguous(), None, L)
+        if fit is None:
+            assert done == 2, name
+            continue
+        assert done == 1 and iters == fit.iters, (name, L, done, iters, fit.iters)
+        assert abs(alpha - fit.alpha) <= 1e-11 * abs(fit.alpha), (name, alpha, fit.alpha)
+
+
+def _run_small(ops, x, du, L):
+    v = torch.empty(x.numel(), device="cuda:0")
+    st = ops.new_fp_state()
+    ops.fixed_point_sorted(dev(x), None if du is None else dev(du), v, L, st)
+    return ops.read_fp_state(st), v
+
+
+@pytest.mark.parametrize("L", [32, 64, 100, 256])
+@pytest.mark.parametrize("n", [1, 63, 96, 864, 3456, 4096])
+def test_sorted_value_fixed_point_matches_oracle(ops, n, L):
+    """k_fp_sorted (many levels, <= 4096 values: the 256-level weights of the first / last conv): alpha <= 1e-11 of the
+    fp64 restatement of project_by_iter (layer_helper.py:40-70), SAME iteration count, v = w* + dual stored."""
+    gen = torch.Generator().manual_seed(n * 7 + L)
+    w = torch.randn(n, generator=gen) * 0.07
+    du = torch.randn(n, generator=gen) * 0.01
+    try:
+        fit = O.fit_scale(w + du, L, -1, 1)
+    except RuntimeWarning:
+        fit = None
+    (alpha, iters, done), v = _run_small(ops, w, du, L)
+    assert torch.equal(v.cpu(), w + du)
+    if fit is None:
+        assert done == 2
+        return
+    assert done == 1 and iters == fit.iters, (done, iters, fit.iters)
+    assert abs(alpha - fit.alpha) <= 1e-11 * abs(fit.alpha), (alpha, fit.alpha)
+
+
+@pytest.mark.parametrize("L", [64, 256])
+def test_sorted_value_fixed_point_on_adversarial_values(ops, L):
+    """Values ON rounding boundaries of the converged and of the start scale (and one ulp either side), zeros, signed
+    zeros, denormals, duplicates, an outlier, all-equal / two-valued tensors: positions found by the galloping search
+    must be exactly the reference's level counts."""
+    gen = torch.Generator().manual_seed(4321 + L)
+    base = torch.randn(3000, generator=gen) * 0.1
+    fit0 = O.fit_scale(base, L, -1, 1)
+    d = 2.0 / (L - 1)
+    bnd = torch.tensor([(k - 0.5) * d - 1.0 for k in range(1, L)], dtype=torch.float64)
+    pts = []
+    for a in (fit0.alpha, base.abs().double().mean().item()):
+        p = (bnd * a).float()
+        pts += [p[::4], torch.nextafter(p, torch.tensor(10.0))[1::4], torch.nextafter(p, torch.tensor(-10.0))[2::4]]
+    cases = {"on boundaries": torch.cat([base] + pts)[:4096],
+             "zeros and tiny": torch.cat([base, torch.zeros(300), -torch.zeros(200), torch.full((100,), -1e-30),
+                                          torch.full((100,), 1e-30), torch.full((50,), -1e-42)]),
+             "duplicates": torch.round(base * 50) / 50,
+             "all equal": torch.full((2000,), 0.37),
+             "two values": torch.cat([torch.full((1500,), -0.2), torch.full((1000,), 0.9)])}
+    out = base.clone()
+    out[0] = 500.0
+    cases["outlier"] = out
+    for name, x in cases.items():
+        try:
+            fit = O.fit_scale(x, L, -1, 1)
+        except RuntimeWarning:
+            fit = None
+        (alpha, iters, done), _ = _run_small(ops, x.contiguous(), None, L)
         if fit is None:
             assert done == 2, name
             continue

@@ -41,12 +41,13 @@ def test_product_path_refuses_cpu_tensors():
 
 
 # ------------------------------------------------------------------ graph / state_dict / BN fold / masks
-def _tiny(task, L=4):
+def _tiny(task, L=4, width=None):
     from efficientq_amd import config as Cf
+    base = dict(Cf.TINY_NET, width=width) if width else Cf.TINY_NET
     if task == "lits":
-        args = Cf.make_args(Cf.TINY_NET, L, L, lwq_batchsz=2)
+        args = Cf.make_args(base, L, L, lwq_batchsz=2)
     else:
-        net = dict(Cf.TINY_NET, task="brats", nMod=2, nClass=4, multi_label="brats", init_stride="2,2,2")
+        net = dict(base, task="brats", nMod=2, nClass=4, multi_label="brats", init_stride="2,2,2")
         args = Cf.make_args(net, L, L, lwq_batchsz=2)
     QConv, info, kwQ = Cf.get_conv_class(args)
     cube, _ = Cf.get_model_cube(args, QConv, kwQ)
