@@ -188,7 +188,7 @@ class OpTimer:
             if kind == "loss" and r.loss_kind == 4:
                 key = ("gram_loss@loop", r.c2, r.n)
             elif kind == "loss":
-                name = {0: "conv_step", 1: "conv_step_i8", 2: "conv_step_i8s", 3: "conv_step_i8_pair"}[r.loss_kind] + "@loop"
+                name = {0: "conv_step", 1: "conv_step_i8", 2: "conv_step_i8s"}[r.loss_kind] + "@loop"
                 key = (name, g.N, g.C1, g.C2, g.D, g.H, g.W, g.KD, g.SD)
             else:
                 key = (kind, r.c2, r.n)
@@ -198,7 +198,7 @@ class OpTimer:
     @staticmethod
     def _work(key):
         op = key[0].replace("@loop", "")
-        if op in ("conv_step", "conv_step_i8", "conv_step_i8s", "conv_step_i8_pair", "gram", "gram_i8"):
+        if op in ("conv_step", "conv_step_i8", "conv_step_i8s", "gram", "gram_i8"):
             N, c1, c2, D, H, W, k, s = key[1:]
             od, oh, ow = (D + 2 * (k // 2) - k) // s + 1, (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
             V, Vin = N * od * oh * ow, N * D * H * W
@@ -209,12 +209,6 @@ class OpTimer:
                 return ("hbm", 4.0 * c2 * V + 1.0 * c1 * Vin, PEAK_HBM_GBS, "GB/s",
                         f"k_conv3d_i8s ({c1}->{c2}, {k}^3/s{s}, {N}x{od}x{oh}x{ow} voxels: 4*c2 B of target + c1 B of "
                         f"level ids per input voxel, i8 MFMA exact)")
-            if op == "conv_step_i8_pair":
-                # 4*(c1 V_in + c2 V) bytes per evaluation in fp32; here level ids are 1 byte, and ONE launch
-                # evaluates TWO iterates (units per launch = 2): the second shares the pass over x and y
-                return ("hbm", 2.0 * (4.0 * c2 * V + 1.0 * c1 * Vin), PEAK_HBM_GBS, "GB/s",
-                        f"k_conv3d_i8p<2> ({c1}->{c2}, 3^3, {N}x{od}x{oh}x{ow} voxels, TWO iterates per launch: 2 x (4*c2 B "
-                        f"of target + c1 B of level ids per voxel) algorithmic, one pass over x and y, i8 MFMA exact)")
             if op == "conv_step_i8":
                 return ("hbm", 4.0 * c2 * V + 1.0 * c1 * Vin, PEAK_HBM_GBS, "GB/s",
                         f"k_conv3d_i8 ({c1}->{c2}, 3^3, {N}x{od}x{oh}x{ow} voxels: 4*c2 B of target + c1 B of level "
@@ -269,8 +263,6 @@ class OpTimer:
                 launches, stream = len(ms), "side"
             else:
                 launches, stream = len(ms) * SAMPLE, ("loss" if key[0].endswith("@loop") else "main")
-                if key[0].startswith("conv_step_i8_pair"):
-                    launches = len(ms) * SAMPLE // 2          # one launch per two iterations
             items.append((key, ms, launches, stream))
         busy = {"main": 0.0, "loss": 0.0, "side": 0.0}
         for key, ms, launches, stream in items:

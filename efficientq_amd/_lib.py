@@ -48,16 +48,6 @@ _P, _SZ, _I, _F, _D, _LL = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_doubl
 _GP = C.POINTER(Geom)
 
 
-class ChainArgs(C.Structure):
-    """effq_chain_args of include/effq_hip.h."""
-    _fields_ = [("B0", C.c_void_p), ("Ainv", C.c_void_p), ("W0", C.c_void_p), ("b0", C.c_void_p),
-                ("G_prev", C.c_void_p), ("dual", C.c_void_p), ("wstar", C.c_void_p), ("bstar", C.c_void_p),
-                ("v", C.c_void_p), ("G", C.c_void_p), ("Gq", C.c_void_p), ("state", C.c_void_p),
-                ("err_flag", C.c_void_p), ("prox_ws", C.c_void_p), ("prox_ws_bytes", C.c_size_t),
-                ("red_ws", C.c_void_p), ("c2", C.c_int32), ("n", C.c_int32), ("has_bias", C.c_int32),
-                ("levels", C.c_int32), ("shift_terms", C.c_int32), ("max_iter", C.c_int32), ("rho", C.c_double),
-                ("eta", C.c_double), ("rho_inv", C.c_double), ("tol", C.c_double), ("dual_div", C.c_float)]
-
 class AdmmRunArgs(C.Structure):
     """effq_admm_run_args of include/effq_hip.h."""
     _fields_ = [("A0", C.c_void_p), ("B0", C.c_void_p), ("W0", C.c_void_p), ("b0", C.c_void_p),
@@ -111,9 +101,6 @@ SIGNATURES = {
     "effq_fp_bucket_ws_bytes": (_SZ, [_SZ]),
     "effq_fixed_point_bucket": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _SZ, _P]),
     "effq_fp_check": (_I, [_P, _P, _P]),
-    "effq_conv_i8_pair_supported": (_I, [_GP, _I, _I]),
-    "conv3d_calib_step_i8_pair": (_I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, _GP, _P, _I,
-                                      C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p), _P, _SZ, _P]),
     "effq_gram_packed_elems": (_SZ, [_I, _I]),
     "effq_gram_pack": (_I, [_P, _P, _I, _I, _P, _P]),
     "effq_gram_unpack": (_I, [_P, _I, _I, _P, _P, _P]),
@@ -147,7 +134,6 @@ SIGNATURES = {
     "effq_prox_ws_bytes": (_SZ, [_I, _I]),
     "effq_prox_solve": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _D, _D, _P, _P, _P, _SZ, _P]),
     "effq_prox_solve_shifted": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _D, _D, _D, _I, _P, _P, _P, _SZ, _P]),
-    "effq_admm_chain_step": (_I, [C.POINTER(ChainArgs), _P]),
     "effq_admm_presum": (_I, [_P, _P, _P, _SZ, _P]),
     "effq_admm_project_dual": (_I, [_P, _P, _P, _I, _P, _P, _F, _P, _SZ, _P]),
     "effq_conv_i8_supported": (_I, [_GP, _I, _I]),
@@ -156,7 +142,6 @@ SIGNATURES = {
     "conv3d_calib_step_i8s": (_I, [_P, _P, _P, _P, _GP, _P, _I, _P, _I, _I, _P, _P, _SZ, _P]),
     "effq_conv_i8_ws_bytes": (_SZ, [_GP]),
     "conv3d_calib_step_i8": (_I, [_P, _P, _P, _P, _GP, _P, _I, _P, _I, _P, _P, _SZ, _P]),
-    "effq_admm_keep_best": (_I, [_P, _P, _I, _P, _P, _P, _P, _SZ, _SZ, _P]),
     "effq_conv_ws_bytes": (_SZ, [_GP]),
     "conv3d_quant_calib_step": (_I, [_P, _P, _P, _P, _P, _GP, _P, _I, _P, _P, _P, _SZ, _P]),
     "effq_adam_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _I, _SZ, _P]),

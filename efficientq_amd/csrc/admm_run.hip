@@ -208,12 +208,6 @@ int effq_admm_run(const effq_admm_run_args* a) {
     set_error("admm_run: fixed-point workspace %zu < %zu", a->fp_ws_bytes, effq_fp_bucket_ws_bytes(nw));
     return EFFQ_ERR_WORKSPACE;
   }
-  // two iterates per pass over x and y (conv3d_calib_step_i8_pair): 17 % less conv time per iterate alone, but its
-  // one-workgroup-per-CU footprint keeps the chain kernels of the next iterations off the CUs (1240 vs 1224 ms per
-  // calibration): opt-in
-  static const bool pair_on = getenv("EFFQ_I8_PAIR") != nullptr && atoi(getenv("EFFQ_I8_PAIR")) != 0;
-  const bool pair = pair_on && a->loss_kind == 1 &&
-                    effq_conv_i8_pair_supported(&a->geom, a->act_levels, a->w_levels) != 0;
   const RhoPlan plan = plan_rhos(a->rho, a->rho_max, a->iters, a->rho_period);
   EFFQ_CHECK_ARG(!plan.overflow);
   const int first = plan.shifted_first ? 1 : 0;
@@ -311,7 +305,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
   double rho = a->rho;
   int cur = -1;     // index into plan.rho of the inverse in use
   static const bool fuse_off = getenv("EFFQ_FUSE_BUILD") != nullptr && atoi(getenv("EFFQ_FUSE_BUILD")) == 0;   // A/B switch
-  const bool fuse_build = !fuse_off && !pair;
+  const bool fuse_build = !fuse_off;
   int bm_ld = 0;
   float* bm = effq_prox_bm(a->prox_ws, c2, n, &bm_ld);
   bool bm_ready = false;
@@ -375,29 +369,15 @@ int effq_admm_run(const effq_admm_run_args* a) {
       }
     }
     p_pr.close();
-    // ---- the loss of this iterate (loss stream); 32 -> 32 layers evaluate two iterates per pass ----
-    const bool last = (i == a->iters - 1);
-    if (pair && (i & 1) == 0 && !last) {
-      if (i % a->rho_period == 0) rho = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
-      continue;                               // evaluated together with iterate i + 1
-    }
+    // ---- the loss of this iterate (loss stream) ----
     if (fork_loss) {
       hipEvent_t e = ev_main[i % EV_POOL];
       ADMM_HIP(hipEventRecord(e, s_main));
       ADMM_HIP(hipStreamWaitEvent(s_loss, e, 0));
     }
     double* sq = a->hist + 2 * (size_t)i;
-    ProfScope p_loss(prof || (pair && g_prof_every > 0 && ((i - 1) % g_prof_every) == g_prof_every / 2), PROF_LOSS, i, a,
-                     s_loss);
-    if (pair && (i & 1) == 1) {
-      const int8_t* gq2[2] = {Gq - nw, Gq};
-      const float* b2[2] = {has_b ? bstar - c2 : nullptr, bstar};
-      const effq_fp_state* st2[2] = {st - 1, st};
-      double* sq2[2] = {sq - 2, sq};
-      p_loss.rec.loss_kind = 3;               // (profiler: the paired form)
-      ADMM_RC(conv3d_calib_step_i8_pair(a->xidx, gq2, b2, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, st2,
-                                        a->w_levels, sq2, a->conv_ws, a->conv_ws_bytes, s_loss));
-    } else if (a->loss_kind == 1)
+    ProfScope p_loss(prof, PROF_LOSS, i, a, s_loss);
+    if (a->loss_kind == 1)
       ADMM_RC(conv3d_calib_step_i8(a->xidx, Gq, bstar, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, st,
                                    a->w_levels, sq, a->conv_ws, a->conv_ws_bytes, s_loss));
     else if (a->loss_kind == 2)

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Para
     return r;
   };
   // per-thread staging constants (independent of the tile); all tile loads are unconditional on clamped
-  // coordinates with validity bits applied at the consumer (see k_conv3d_i8l)
+  // coordinates with validity bits applied at the consumer (see k_conv3d_i8l2)
   int hcd[NHL], hch[NHL], hcw[NHL], hpart[NHL];
 #pragma unroll
   for (int k = 0; k < NHL; ++k) {
@@ -554,168 +554,13 @@ __global__ __launch_bounds__(256, (CG == 1) ? 2 : 1) void k_conv3d_i8(ConvI8Para
 }
 
 
-// 32-input-channel variant tuned for memory-level parallelism (the kernel is HBM-latency bound):
-//  * B operands (27 KB) live in LDS, laid out [tap][k-half][out channel][16 B] (conflict-free ds_read_b128),
-//    which frees ~108 VGPRs -> three workgroups per CU;
-//  * two register sets alternate roles so that halo and targets are fetched TWO tiles ahead;
-//  * targets are fetched in accumulator layout (16 dword loads per lane, 128-byte segments), so the epilogue
-//    needs no LDS transpose and a tile costs two barriers.
-__global__ __launch_bounds__(256, 3) void k_conv3d_i8l(ConvI8Params p) {
-  constexpr int VS = 48, PADB = halo_row_pad(1);
-  constexpr int NHL = (I_NH * 2 + 255) / 256;   // 3
-  __shared__ __attribute__((aligned(16))) int8_t wl[27 * 2 * 32 * 16];
-  __shared__ __attribute__((aligned(16))) int8_t halo[I_NH * VS + I_HD * I_HH * PADB];
-  __shared__ double red_smem[2 * 16];
-  __shared__ int s_last;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  const int ch0 = blockIdx.y * 32;
-  const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int t_begin = (int)blockIdx.x * per;
-  const int t_end = (t_begin + per < p.ntiles) ? t_begin + per : p.ntiles;
-
-  // stage this workgroup's weights once: wl[tap][h][j] <- wq[(tap*c2p + ch0 + j)*32 + 16h]
-  for (int u = tid; u < 27 * 2 * 32; u += 256) {
-    const int j = u & 31, h = (u >> 5) & 1, tap = u >> 6;
-    *reinterpret_cast<v4i*>(&wl[u * 16]) =
-        *reinterpret_cast<const v4i*>(p.wq + ((size_t)(tap * p.c2p + ch0 + j) * 32 + 16 * h));
-  }
-  const float scale = (float)((double)(*p.act_alpha) * (double)(float)p.wstate->alpha * p.inv_levels);
-  const float bv = (p.bias != nullptr) ? p.bias[ch0 + li] : 0.0f;
-
-  struct Tile {
-    int n, od0, oh0, ow0;
-  };
-  auto decode = [&](int tile) {
-    Tile r;
-    int t = tile;
-    r.ow0 = (t % p.tiles_w) * ITW;
-    t /= p.tiles_w;
-    r.oh0 = (t % p.tiles_h) * ITH;
-    t /= p.tiles_h;
-    r.od0 = (t % p.tiles_d) * ITD;
-    r.n = t / p.tiles_d;
-    return r;
-  };
-  // Per-thread constants of the staging roles (independent of the tile): halo cell (hd,hh,hw,part) of each of the
-  // NHL 16-byte loads, and the (row, column) of the 16 accumulator registers inside the wave's 4x8 voxel plane.
-  int hcd[NHL], hch[NHL], hcw[NHL];
-#pragma unroll
-  for (int k = 0; k < NHL; ++k) {
-    const int u = tid + k * 256;
-    const int vox = (u < I_NH * 2) ? (u >> 1) : 0;
-    hcw[k] = vox % I_HW;
-    const int t2 = vox / I_HW;
-    hch[k] = t2 % I_HH;
-    hcd[k] = (u < I_NH * 2) ? (t2 / I_HH) : (1 << 20);   // out-of-range depth marks the unused slots invalid
-  }
-  const int part16 = (tid & 1) * 16;
-
-  // All loads of a tile are UNCONDITIONAL on clamped coordinates (a load under a branch is waited for inside the
-  // branch and the two-tile prefetch collapses); validity travels as bit masks and is applied where the values
-  // are consumed (halo: at the LDS store; targets: at the loss accumulation).
-  struct Regs {
-    v4i h[NHL];
-    float y[16];
-    unsigned hmask, ymask;
-  };
-  auto fetch = [&](int tile, Regs& R) {
-    const Tile tl = decode(tile);
-    const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
-    const size_t nbase = (size_t)tl.n * p.D;
-    unsigned hm = 0;
-#pragma unroll
-    for (int k = 0; k < NHL; ++k) {
-      const int id = id0 + hcd[k], ih = ih0 + hch[k], iw = iw0 + hcw[k];
-      const bool ok = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-      const int cd = min(max(id, 0), p.D - 1), chh = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
-      hm |= (ok ? 1u : 0u) << k;
-      R.h[k] = *reinterpret_cast<const v4i*>(p.x + (((nbase + cd) * p.H + chh) * p.W + cw) * 32 + part16);
-    }
-    R.hmask = (EFFQ_DBG(p) == 2) ? 0u : hm;
-    // targets: register r holds voxel (row r>>2, column (r&3) + 4*lh) of d-plane wid, channel ch0 + li
-    const int od = min(tl.od0 + wid, p.OD - 1);
-    const bool dok = tl.od0 + wid < p.OD;
-    const size_t ybase = (((size_t)tl.n * p.OD + od) * p.OH) * p.OW;
-    size_t rowoff[4];
-    int coloff[4];
-    unsigned rowok = 0, colok = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int oh = tl.oh0 + q, ow = tl.ow0 + q + 4 * lh;
-      rowok |= (unsigned)(oh < p.OH) << q;
-      colok |= (unsigned)(ow < p.OW) << q;
-      rowoff[q] = (ybase + (size_t)min(oh, p.OH - 1) * p.OW) * p.C2 + ch0 + li;
-      coloff[q] = min(ow, p.OW - 1) * p.C2;
-    }
-    unsigned ym = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      R.y[r] = p.y[rowoff[r >> 2] + coloff[r & 3]];
-      ym |= (((rowok >> (r >> 2)) & (colok >> (r & 3)) & 1u) & (dok ? 1u : 0u)) << r;
-    }
-    R.ymask = (EFFQ_DBG(p) == 3) ? 0u : ym;
-  };
-
-  const int hv = (wid * I_HH + (li >> 3)) * I_HW + (li & 7);
-  double l0 = 0.0;
-  // one tile: store X's halo, refill X with tile+2, MFMAs, register epilogue against X's (saved) targets
-  auto body = [&](int tile, Regs& X, bool more) {
-    lds_barrier();                                       // previous tile's MFMAs are done with the halo
-#pragma unroll
-    for (int k = 0; k < NHL; ++k) {
-      const int u = tid + k * 256;
-      const v4i val = ((X.hmask >> k) & 1u) ? X.h[k] : v4i{0, 0, 0, 0};
-      if (u < I_NH * 2) *reinterpret_cast<v4i*>(&halo[(u >> 1) * VS + ((u >> 1) / I_HW) * PADB + (u & 1) * 16]) = val;
-    }
-    float ycur[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ycur[r] = X.y[r];
-    const unsigned ymcur = X.ymask;
-    lds_barrier();
-    fetch(more ? tile + 2 : tile, X);                      // two tiles ahead, into the set just consumed (the last
-                                                           // two tiles harmlessly re-read themselves)
-    __builtin_amdgcn_sched_barrier(0);
-    v16i acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0;
-    if (EFFQ_DBG(p) != 1)
-#pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-      const v4i a = *reinterpret_cast<const v4i*>(halo + (hv + (kd * I_HH + kh) * I_HW + kw) * VS +
-                                                  (wid * I_HH + (li >> 3) + kd * I_HH + kh) * PADB + 16 * lh);
-      const v4i b = *reinterpret_cast<const v4i*>(&wl[((tap * 2 + lh) * 32 + li) * 16]);
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float d = ((float)acc[r] * scale + bv) - ycur[r];
-      l0 += ((ymcur >> r) & 1u) ? (double)(d * d) : 0.0;
-    }
-  };
-
-  Regs A, B;
-#pragma unroll
-  for (int k = 0; k < NHL; ++k) A.h[k] = B.h[k] = v4i{0, 0, 0, 0};
-#pragma unroll
-  for (int r = 0; r < 16; ++r) A.y[r] = B.y[r] = 0.0f;
-  A.hmask = A.ymask = B.hmask = B.ymask = 0;
-  if (t_begin < t_end) fetch(t_begin, A);
-  if (t_begin + 1 < t_end) fetch(t_begin + 1, B);
-  for (int tile = t_begin; tile < t_end; tile += 2) {
-    body(tile, A, tile + 2 < t_end);
-    if (tile + 1 < t_end) body(tile + 1, B, tile + 3 < t_end);
-  }
-  double v[2] = {l0, l0};
-  grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
-                     gridDim.x * gridDim.y);
-}
-
-// Two-plane variant of k_conv3d_i8l: a workgroup tile is 8x4x8 output voxels, wave w owns d-planes w and w+4 and
-// feeds BOTH accumulators from one read of the B operand (the LDS operand traffic limits k_conv3d_i8l: 27 x 2 KB
-// per wave-tile); barriers, tile decoding and halo overlap are amortised over twice the voxels.  2 workgroups/CU.
+// 32-input-channel kernel, tuned for memory-level parallelism (it is HBM-latency bound): B operands (27 KB) live in LDS,
+// laid out [tap][k-half][out channel][16 B] (conflict-free ds_read_b128); two register sets alternate roles so that halo
+// and targets are fetched TWO tiles ahead; targets are fetched in accumulator layout (16 dword loads per lane, 128-byte
+// segments), so the epilogue needs no LDS transpose.  A workgroup tile is 8x4x8 output voxels, wave w owns d-planes w and
+// w+4 and feeds BOTH accumulators from one read of the B operand (a one-plane tile was bound by its LDS operand traffic,
+// 27 x 2 KB per wave-tile); barriers, tile decoding and halo overlap are amortised over twice the voxels.  2 workgroups
+// per CU.  This variant takes ragged volumes and any C2 % 32 == 0; k_conv3d_i8l2e is its fast path.
 constexpr int L2_TD = 8;
 constexpr int L2_HD = L2_TD + 2, L2_NH = L2_HD * I_HH * I_HW;    // 600 halo voxels
 __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2(ConvI8Params p) {
@@ -1185,209 +1030,6 @@ __global__ __launch_bounds__(512, 1) void k_conv3d_i8w(ConvI8Params p) {
   grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
 }
 
-// ---- 32 channels, NB iterates per pass ---------------------------------------------------------------------------
-// The per-iteration loss of the 32-channel layers is bound by the stream of fp32 targets (128 B per voxel against 32 B
-// of level ids), not by the contraction, and the loss of an iterate is only needed when the best one is picked after
-// the loop (effq_admm_run keeps every iterate in a ring).  So ONE pass over x and y evaluates NB = 2 consecutive
-// iterates: their weights are 2 x 32 output columns of one implicit GEMM (each A operand read from the halo tile feeds
-// two MFMAs), each with its own scale, bias and squared-error sum against the same targets.  Integer arithmetic per
-// iterate is unchanged: the sums are bit-identical to two single passes.
-// Workgroup = 8 waves, tile = 16 x 4 x 8 output voxels (wave w owns d-planes w and w + 8), both weight sets resident
-// in LDS (2 x 27 KB) beside the 18 x 6 x 10 halo tile (51 KB): one workgroup per CU, 8 waves, halo re-read 2.1x in
-// LDS terms against 2.34x for the 8-plane tile.
-constexpr int P_TD = 16;
-constexpr int P_HD = P_TD + 2, P_NH = P_HD * I_HH * I_HW;    // 1080 halo voxels
-struct ConvI8PairParams {
-  ConvI8Params b;             // set 0 (wq, bias, wstate, sqerr)
-  const int8_t* wq1;          // set 1
-  const float* bias1;
-  const effq_fp_state* wstate1;
-  double* sqerr1;
-  double* tmp;                // 2 doubles of workspace
-};
-template <int NB>
-__global__ __launch_bounds__(512, 1) void k_conv3d_i8p(ConvI8PairParams pp) {
-  const ConvI8Params& p = pp.b;
-  constexpr int VS = 48, PADB = halo_row_pad(1);
-  constexpr int NHL = (P_NH * 2 + 511) / 512;   // 5
-  extern __shared__ __attribute__((aligned(16))) int8_t dyn_lds[];
-  int8_t* wl = dyn_lds;                                         // [NB][27][2][32][16]
-  int8_t* halo = dyn_lds + NB * 27 * 2 * 32 * 16;               // P_NH * VS
-  __shared__ double red_smem[2 * 16];
-  __shared__ int s_last;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int t_begin = (int)blockIdx.x * per;
-  const int t_end = (t_begin + per < p.ntiles) ? t_begin + per : p.ntiles;
-
-#pragma unroll
-  for (int s = 0; s < NB; ++s) {
-    const int8_t* wq = (s == 0) ? p.wq : pp.wq1;
-    for (int u = tid; u < 27 * 2 * 32; u += 512) {
-      const int j = u & 31, h = (u >> 5) & 1, tap = u >> 6;
-      *reinterpret_cast<v4i*>(&wl[(s * 27 * 2 * 32 + u) * 16]) =
-          *reinterpret_cast<const v4i*>(wq + ((size_t)(tap * p.c2p + j) * 32 + 16 * h));
-    }
-  }
-  float scale[NB], bv[NB];
-#pragma unroll
-  for (int s = 0; s < NB; ++s) {
-    const effq_fp_state* ws = (s == 0) ? p.wstate : pp.wstate1;
-    const float* bias = (s == 0) ? p.bias : pp.bias1;
-    scale[s] = (float)((double)(*p.act_alpha) * (double)(float)ws->alpha * p.inv_levels);
-    bv[s] = (bias != nullptr) ? bias[li] : 0.0f;
-  }
-
-  struct Tile {
-    int n, od0, oh0, ow0;
-  };
-  auto decode = [&](int tile) {           // p.tiles_d counts 16-plane tiles for this kernel
-    Tile r;
-    int t = tile;
-    r.ow0 = (t % p.tiles_w) * ITW;
-    t /= p.tiles_w;
-    r.oh0 = (t % p.tiles_h) * ITH;
-    t /= p.tiles_h;
-    r.od0 = (t % p.tiles_d) * P_TD;
-    r.n = t / p.tiles_d;
-    return r;
-  };
-  int hcd[NHL], hch[NHL], hcw[NHL];
-#pragma unroll
-  for (int k = 0; k < NHL; ++k) {
-    const int u = tid + k * 512;
-    const int vox = (u < P_NH * 2) ? (u >> 1) : 0;
-    hcw[k] = vox % I_HW;
-    const int t2 = vox / I_HW;
-    hch[k] = t2 % I_HH;
-    hcd[k] = (u < P_NH * 2) ? (t2 / I_HH) : (1 << 20);
-  }
-  const int part16 = (tid & 1) * 16;
-
-  struct Regs {
-    v4i h[NHL];
-    float y[2][16];
-    unsigned hmask, ymask[2];
-  };
-  auto fetch = [&](int tile, Regs& R) {
-    const Tile tl = decode(tile);
-    const int id0 = tl.od0 - p.PD, ih0 = tl.oh0 - p.PH, iw0 = tl.ow0 - p.PW;
-    const size_t nbase = (size_t)tl.n * p.D;
-    unsigned hm = 0;
-#pragma unroll
-    for (int k = 0; k < NHL; ++k) {
-      const int id = id0 + hcd[k], ih = ih0 + hch[k], iw = iw0 + hcw[k];
-      const bool ok = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-      const int cd = min(max(id, 0), p.D - 1), chh = min(max(ih, 0), p.H - 1), cw = min(max(iw, 0), p.W - 1);
-      hm |= (ok ? 1u : 0u) << k;
-      R.h[k] = *reinterpret_cast<const v4i*>(p.x + (((nbase + cd) * p.H + chh) * p.W + cw) * 32 + part16);
-    }
-    R.hmask = hm;
-    unsigned rowok = 0, colok = 0;
-    size_t rowrel[4];
-    int coloff[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int oh = tl.oh0 + q, ow = tl.ow0 + q + 4 * lh;
-      rowok |= (unsigned)(oh < p.OH) << q;
-      colok |= (unsigned)(ow < p.OW) << q;
-      rowrel[q] = (size_t)min(oh, p.OH - 1) * p.OW * p.C2;
-      coloff[q] = min(ow, p.OW - 1) * p.C2 + li;
-    }
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      const int odr = tl.od0 + wid + 8 * pl;
-      const int od = min(odr, p.OD - 1);
-      const bool dok = odr < p.OD;
-      const size_t ybase = (((size_t)tl.n * p.OD + od) * p.OH) * p.OW * p.C2;
-      unsigned ym = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        R.y[pl][r] = p.y[ybase + rowrel[r >> 2] + coloff[r & 3]];
-        ym |= (((rowok >> (r >> 2)) & (colok >> (r & 3)) & 1u) & (dok ? 1u : 0u)) << r;
-      }
-      R.ymask[pl] = ym;
-    }
-  };
-
-  const int hv0 = (wid * I_HH + (li >> 3)) * I_HW + (li & 7);
-  const int hv1 = hv0 + 8 * I_HH * I_HW;
-  const int hb0 = hv0 * VS + (wid * I_HH + (li >> 3)) * PADB, hb1 = hv1 * VS + ((wid + 8) * I_HH + (li >> 3)) * PADB;
-  double lsum[NB];
-#pragma unroll
-  for (int s = 0; s < NB; ++s) lsum[s] = 0.0;
-  auto body = [&](int tile, Regs& X, bool more) {
-    lds_barrier();
-#pragma unroll
-    for (int k = 0; k < NHL; ++k) {
-      const int u = tid + k * 512;
-      const v4i val = ((X.hmask >> k) & 1u) ? X.h[k] : v4i{0, 0, 0, 0};
-      if (u < P_NH * 2) *reinterpret_cast<v4i*>(&halo[(u >> 1) * VS + ((u >> 1) / I_HW) * PADB + (u & 1) * 16]) = val;
-    }
-    float ycur[2][16];
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ycur[pl][r] = X.y[pl][r];
-    const unsigned ym0 = X.ymask[0], ym1 = X.ymask[1];
-    lds_barrier();
-    fetch(more ? tile + 2 : tile, X);
-    __builtin_amdgcn_sched_barrier(0);
-    v16i acc[NB][2];
-#pragma unroll
-    for (int s = 0; s < NB; ++s)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[s][0][r] = acc[s][1][r] = 0;
-#pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-      const int toff = ((kd * I_HH + kh) * I_HW + kw) * VS + (kd * I_HH + kh) * PADB + 16 * lh;
-      const v4i a0 = *reinterpret_cast<const v4i*>(halo + hb0 + toff);
-      const v4i a1 = *reinterpret_cast<const v4i*>(halo + hb1 + toff);
-#pragma unroll
-      for (int s = 0; s < NB; ++s) {
-        const v4i b = *reinterpret_cast<const v4i*>(&wl[((s * 27 + tap) * 2 + lh) * 32 * 16 + li * 16]);
-        acc[s][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b, acc[s][0], 0, 0, 0);
-        acc[s][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b, acc[s][1], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < NB; ++s) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float d0 = ((float)acc[s][0][r] * scale[s] + bv[s]) - ycur[0][r];
-        const float d1 = ((float)acc[s][1][r] * scale[s] + bv[s]) - ycur[1][r];
-        lsum[s] += ((ym0 >> r) & 1u) ? (double)(d0 * d0) : 0.0;
-        lsum[s] += ((ym1 >> r) & 1u) ? (double)(d1 * d1) : 0.0;
-      }
-    }
-  };
-
-  Regs A, B;
-#pragma unroll
-  for (int k = 0; k < NHL; ++k) A.h[k] = B.h[k] = v4i{0, 0, 0, 0};
-#pragma unroll
-  for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) A.y[pl][r] = B.y[pl][r] = 0.0f;
-  A.hmask = B.hmask = 0;
-  A.ymask[0] = A.ymask[1] = B.ymask[0] = B.ymask[1] = 0;
-  if (t_begin < t_end) fetch(t_begin, A);
-  if (t_begin + 1 < t_end) fetch(t_begin + 1, B);
-  for (int tile = t_begin; tile < t_end; tile += 2) {
-    body(tile, A, tile + 2 < t_end);
-    if (tile + 1 < t_end) body(tile + 1, B, tile + 3 < t_end);
-  }
-  double v[2] = {lsum[0], lsum[NB - 1]};
-  grid_sum_finish<2>(v, p.partials, p.ticket, pp.tmp, red_smem, &s_last);
-  if (s_last && tid == 0) {       // (thread 0 of the last block wrote tmp itself)
-    p.sqerr[0] = p.sqerr[1] = pp.tmp[0];
-    if (NB == 2) pp.sqerr1[0] = pp.sqerr1[1] = pp.tmp[1];
-  }
-}
-
 struct I8Plan {
   ConvI8Params p;
   dim3 grid;
@@ -1398,10 +1040,7 @@ static bool i8_stream64() {
   static const int on = getenv("EFFQ_I8G64") ? atoi(getenv("EFFQ_I8G64")) : 0;
   return on != 0;
 }
-static bool i8_two_plane(const effq_geom* g) {
-  static const int on = getenv("EFFQ_I8L2") ? atoi(getenv("EFFQ_I8L2")) : 1;
-  return on != 0 && g->C1 == 32;
-}
+static bool i8_two_plane(const effq_geom* g) { return g->C1 == 32; }
 
 static int i8_plan(const effq_geom* g, I8Plan* pl) {
   EFFQ_CHECK_ARG(g != nullptr);
@@ -1423,10 +1062,9 @@ static int i8_plan(const effq_geom* g, I8Plan* pl) {
   EFFQ_CHECK_ARG(nt < (1ll << 30));
   p.ntiles = (int)nt;
   const int ny = (g->C1 == 512) ? p.C2 / 64 : p.C2 / 32;
-  static const int wpc1 = getenv("EFFQ_I8_WPC") ? atoi(getenv("EFFQ_I8_WPC")) : 3;   // tuning aid (one-plane kernel)
   static const int wpc128 = getenv("EFFQ_I8_WPC128") ? atoi(getenv("EFFQ_I8_WPC128")) : 2;   // tuning aid
   static const int wpc64 = getenv("EFFQ_I8_WPC64") ? atoi(getenv("EFFQ_I8_WPC64")) : 2;      // tuning aid
-  const int wg_per_cu = (g->C1 == 32) ? (i8_two_plane(g) ? 2 : wpc1) : (g->C1 == 128) ? wpc128
+  const int wg_per_cu = (g->C1 == 32) ? 2 : (g->C1 == 128) ? wpc128
                         : (g->C1 == 64 && i8_stream64()) ? wpc64 : 1;
   int gx = (256 * wg_per_cu + ny - 1) / ny;
   if (gx < 32) gx = 32;
@@ -1470,85 +1108,10 @@ int effq_conv_i8_supported(const effq_geom* g, int act_levels, int w_levels) {
   return 1;
 }
 
-static size_t i8_pair_need(const effq_geom* g) {
-  // ticket | partials (<= 256 blocks x 2) | tmp | two packed weight sets
-  return 256 + 256 * 2 * sizeof(double) + 64 + 2 * ((size_t)27 * g->C2 * g->C1 + 16) + 256;
-}
-
-int effq_conv_i8_pair_supported(const effq_geom* g, int act_levels, int w_levels) {
-  return effq_conv_i8_supported(g, act_levels, w_levels) && g->C1 == 32 && g->C2 == 32;
-}
-
 size_t effq_conv_i8_ws_bytes(const effq_geom* g) {
   I8Plan pl;
   if (i8_plan(g, &pl) != EFFQ_OK) return 0;
-  size_t need = 256 + pl.nblk * 2 * sizeof(double) + pl.wq_bytes + 256;
-  if (g->C1 == 32 && g->C2 == 32 && i8_pair_need(g) > need) need = i8_pair_need(g);   // serves the paired form too
-  return need;
-}
-
-int conv3d_calib_step_i8_pair(const uint8_t* xidx_ndhwc, const int8_t* const* Gq, const float* const* bias,
-                              const float* y_fp, const effq_geom* g, const float* act_alpha_dev, int act_levels,
-                              const effq_fp_state* const* w_state_dev, int w_levels, double* const* sqerr_out, void* ws,
-                              size_t ws_bytes, void* stream) {
-  EFFQ_CHECK_ARG(xidx_ndhwc && Gq && bias && y_fp && g && act_alpha_dev && w_state_dev && sqerr_out && ws);
-  EFFQ_CHECK_ARG(Gq[0] && Gq[1] && w_state_dev[0] && w_state_dev[1] && sqerr_out[0] && sqerr_out[1]);
-  EFFQ_CHECK_ARG((bias[0] == nullptr) == (bias[1] == nullptr));
-  EFFQ_CHECK_ARG(effq_conv_i8_pair_supported(g, act_levels, w_levels));
-  if (ws_bytes < i8_pair_need(g)) {
-    set_error("conv_i8_pair: workspace %zu < required %zu", ws_bytes, i8_pair_need(g));
-    return EFFQ_ERR_WORKSPACE;
-  }
-  I8Plan pl;
-  int rc = i8_plan(g, &pl);
-  if (rc != EFFQ_OK) return rc;
-  ConvI8PairParams pp;
-  memset(&pp, 0, sizeof(pp));
-  pp.b = pl.p;
-  ConvI8Params& p = pp.b;
-  p.tiles_d = (p.OD + P_TD - 1) / P_TD;
-  const long long nt = (long long)p.N * p.tiles_d * p.tiles_h * p.tiles_w;
-  p.ntiles = (int)nt;
-  int gx = 256;
-  if (gx > p.ntiles) gx = p.ntiles;
-  char* base = reinterpret_cast<char*>(ws);
-  p.ticket = reinterpret_cast<unsigned int*>(base);
-  p.partials = reinterpret_cast<double*>(base + 256);
-  pp.tmp = reinterpret_cast<double*>(base + 256 + 256 * 2 * sizeof(double));
-  const size_t wsz = ((size_t)27 * g->C2 * g->C1 + 15) & ~(size_t)15;
-  int8_t* wq0 = reinterpret_cast<int8_t*>(base + 256 + 256 * 2 * sizeof(double) + 64);
-  wq0 = reinterpret_cast<int8_t*>((reinterpret_cast<uintptr_t>(wq0) + 15) & ~(uintptr_t)15);
-  int8_t* wq1 = wq0 + wsz;
-  p.x = reinterpret_cast<const int8_t*>(xidx_ndhwc);
-  p.wq = wq0;
-  pp.wq1 = wq1;
-  p.bias = bias[0];
-  pp.bias1 = bias[1];
-  p.y = y_fp;
-  p.act_alpha = act_alpha_dev;
-  p.wstate = w_state_dev[0];
-  pp.wstate1 = w_state_dev[1];
-  p.inv_levels = 1.0 / ((double)(act_levels - 1) * (double)(w_levels - 1));
-  p.sqerr = sqerr_out[0];
-  pp.sqerr1 = sqerr_out[1];
-  hipStream_t st = as_stream(stream);
-  {
-    size_t nb = (wsz + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_pack_weight_i8, dim3((unsigned)nb), dim3(256), 0, st, Gq[0], wq0, p.C1, p.C2, 27, p.c2p);
-    hipLaunchKernelGGL(k_pack_weight_i8, dim3((unsigned)nb), dim3(256), 0, st, Gq[1], wq1, p.C1, p.C2, 27, p.c2p);
-    EFFQ_LAUNCH_CHECK();
-  }
-  const size_t lds = (size_t)2 * 27 * 2 * 32 * 16 + (size_t)P_NH * 48 + (size_t)P_HD * I_HH * halo_row_pad(1);
-  static bool attr_set = false;
-  if (!attr_set) {
-    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_i8p<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_conv3d_i8p<2>, dim3((unsigned)gx), dim3(512), lds, st, pp);
-  EFFQ_LAUNCH_CHECK();
-  return EFFQ_OK;
+  return 256 + pl.nblk * 2 * sizeof(double) + pl.wq_bytes + 256;
 }
 
 int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const float* bias, const float* y_fp,
@@ -1613,14 +1176,10 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
   }
   if (p.C1 == 32) {
     static const bool fast_off = getenv("EFFQ_I8L2E") != nullptr && atoi(getenv("EFFQ_I8L2E")) == 0;   // A/B switch
-    if (i8_two_plane(g) && !fast_off && p.C2 == 32 && p.OD % L2_TD == 0 && p.OH % ITH == 0 && p.OW % ITW == 0)
+    if (!fast_off && p.C2 == 32 && p.OD % L2_TD == 0 && p.OH % ITH == 0 && p.OW % ITW == 0)
       hipLaunchKernelGGL(k_conv3d_i8l2e, pl.grid, dim3(256), 0, st, p);
-    else if (i8_two_plane(g))
-      hipLaunchKernelGGL(k_conv3d_i8l2, pl.grid, dim3(256), 0, st, p);
-    else if (effq_ablate_env("EFFQ_I8_REGS") != 0)      // register-resident variant kept for A/B comparison
-      hipLaunchKernelGGL(k_conv3d_i8<1>, pl.grid, dim3(256), 0, st, p);
     else
-      hipLaunchKernelGGL(k_conv3d_i8l, pl.grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL(k_conv3d_i8l2, pl.grid, dim3(256), 0, st, p);
   } else if (p.C1 == 64 && !i8_stream64()) {
     hipLaunchKernelGGL(k_conv3d_i8<2>, pl.grid, dim3(256), 0, st, p);
   } else {

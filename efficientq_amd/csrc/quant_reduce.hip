@@ -1008,39 +1008,6 @@ __global__ __launch_bounds__(TPB) void k_project_dual4(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(TPB) void k_keep_best(const double* __restrict__ sqerr, double* best, int iter,
-                                                   const float* __restrict__ G, const float* __restrict__ b,
-                                                   float* __restrict__ bG, float* __restrict__ bb, size_t nw,
-                                                   size_t nb) {
-  // every thread evaluates the same predicate from the same two doubles (EfficientQConv.py:139-142)
-  const double loss = sqerr[0];
-  const double cur = __hip_atomic_load(&best[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const bool take = (iter == 0) || (loss < cur);
-  if (take) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t i = t0; i < nw; i += stride) bG[i] = G[i];
-    if (b != nullptr)
-      for (size_t i = t0; i < nb; i += stride) bb[i] = b[i];
-  }
-  // best[0..1] are rewritten by the LAST block to get here (ticket in best[2]), i.e. after every block has read
-  // the old value: no follow-up kernel (this runs 200 times per layer on the loss stream, where every launch counts)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned int* ticket = reinterpret_cast<unsigned int*>(best + 2);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (take) {
-        __hip_atomic_store(&best[0], loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        best[1] = (double)iter;
-      }
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 // ---- backward of PTQConv._quantize_act with the straight-through estimator (row f3) ------------------------------------
 // q = discretize(x / alpha, L, 0, 1) * alpha (PTQConv.py:114-116), round with identity gradient (layer_helper.py:13-22),
 // clamp with torch's gradient mask (1 where lo <= u <= hi, bounds included).  With u = x / alpha, r = discretize(u):
@@ -1274,59 +1241,50 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
 
 size_t effq_fp_coop_max(void) { return (size_t)FPC_SLICE * FPC_MAXG; }
 
-// light != 0: workgroups of 512 threads with slices of at most 13824 values (54 KB of LDS): a footprint that fits
-// beside two workgroups of the loss conv on a CU, so the fixed point of iteration i+1 runs DURING the loss conv of
-// iteration i instead of queueing behind it (a 1024-thread single-workgroup fixed point cannot be placed before
-// the persistent conv workgroups retire).
-static int fixed_point_coop_impl(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
-                                 double tol, int max_iter, effq_fp_state* state_dev, void* ws, int light, void* stream) {
+int effq_fp_coop_set_spin_limit(unsigned int polls) {
+  g_fpc_spin_limit = polls ? polls : FPC_SPIN_LIMIT;
+  return EFFQ_OK;
+}
+
+int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                          double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream) {
   EFFQ_CHECK_ARG(a && state_dev && ws && n > 0 && levels >= 2 && hi > lo && max_iter > 0);
   EFFQ_CHECK_ARG(n <= effq_fp_coop_max());
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
   const double d = (hi - lo) / (double)(levels - 1);
-  const size_t slice = light ? (size_t)FPC_SLICE / 2 : (size_t)FPC_SLICE;
-  int G = (int)((n + slice - 1) / slice);
+  int G = (int)((n + FPC_SLICE - 1) / FPC_SLICE);
   if (G < 1) G = 1;
   EFFQ_CHECK_ARG(G <= FPC_MAXG);
   const size_t per = (n + G - 1) / G;
   const size_t lds = per * sizeof(float);
   // workspace: reuse the reduction workspace: partials [2][FPC_MAXG][3] doubles at its start
   double* partials = reinterpret_cast<double*>(ws);
-  // the two counter words sit in the tail of the reduction workspace (after the ticket), where no reduction kernel
-  // writes partial sums: they must still be zero from the previous launch
+  // the counter words sit in the tail of the reduction workspace (after the ticket), where no reduction kernel
+  // writes partial sums: they must still be zero from the previous launch (the kernel leaves them at zero; the
+  // reduction workspace is zero-filled at creation)
   unsigned int* counter = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(ws) +
                                                           sizeof(double) * RED_MAX_BLOCKS * RED_SLOTS + 64);
   hipStream_t st = as_stream(stream);
-  // (the kernel leaves its two counter words at zero; the reduction workspace is zero-filled at creation)
   int dev = 0;
   EFFQ_HIP(hipGetDevice(&dev));
   EFFQ_CHECK_ARG(dev >= 0 && dev < 64);
-  static bool attr_set_dev[64] = {};
-  bool& attr_set = attr_set_dev[dev];
-  if (!attr_set) {
+  // per DEVICE: the LDS attribute of the kernel and the number of workgroups that can be resident at once
+  static bool known[64] = {};
+  static int resident_max[64];
+  if (!known[dev]) {
     EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fp_coop<FPC_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(FPC_SLICE * sizeof(float))));
-    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fp_coop<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(FPC_SLICE * sizeof(float))));
-    attr_set = true;
-  }
-  // The grid barrier needs every workgroup resident at once.  That holds on a whole MI355X (G <= 256 = its CU count,
-  // one workgroup per CU by LDS); on a partitioned device (CPX / DPX), a smaller part, or with the CUs shared, it may
-  // not: then the fixed point runs as one launch per iteration (each a no-op once converged) - slower, never stuck.
-  static int resident_max_dev[64][2];
-  static bool resident_known[64][2] = {};
-  int* resident_max = resident_max_dev[dev];
-  if (!resident_known[dev][light]) {
-    resident_known[dev][light] = true;
     int ncu = 0, per_cu = 0;
     EFFQ_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    if (light)
-      EFFQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fp_coop<512>, 512, FPC_SLICE / 2 * sizeof(float)));
-    else
-      EFFQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fp_coop<FPC_T>, FPC_T, FPC_SLICE * sizeof(float)));
-    resident_max[light] = ncu * per_cu;
+    EFFQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fp_coop<FPC_T>, FPC_T, FPC_SLICE * sizeof(float)));
+    resident_max[dev] = ncu * per_cu;
+    known[dev] = true;
   }
-  if (G > resident_max[light]) {
+  // The grid barrier needs every workgroup resident at once.  That holds on a whole MI355X (G <= 256 = its CU count,
+  // one workgroup per CU by LDS; workgroups of other streams only delay a late arrival: they retire, they never wait
+  // for this kernel); on a partitioned device (CPX / DPX) or a smaller part it may not: then the fixed point runs as one
+  // launch per iteration (each a no-op once converged) - slower, never stuck.
+  if (G > resident_max[dev]) {
     RedWs r = red_ws(ws);
     const float* src = a;
     if (b != nullptr) {
@@ -1344,29 +1302,10 @@ static int fixed_point_coop_impl(const float* a, const float* b, float* v_out, s
     EFFQ_LAUNCH_CHECK();
     return EFFQ_OK;
   }
-  if (light)
-    hipLaunchKernelGGL(k_fp_coop<512>, dim3(G), dim3(512), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol, max_iter,
-                       partials, counter, g_fpc_spin_limit);
-  else
-    hipLaunchKernelGGL(k_fp_coop<FPC_T>, dim3(G), dim3(FPC_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol,
-                       max_iter, partials, counter, g_fpc_spin_limit);
+  hipLaunchKernelGGL(k_fp_coop<FPC_T>, dim3(G), dim3(FPC_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol,
+                     max_iter, partials, counter, g_fpc_spin_limit);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
-}
-
-int effq_fp_coop_set_spin_limit(unsigned int polls) {
-  g_fpc_spin_limit = polls ? polls : FPC_SPIN_LIMIT;
-  return EFFQ_OK;
-}
-
-int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
-                          double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream) {
-  return fixed_point_coop_impl(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, ws, 0, stream);
-}
-
-int effq_fixed_point_coop_light(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
-                                double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream) {
-  return fixed_point_coop_impl(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, ws, 1, stream);
 }
 
 int effq_fp_check(const effq_fp_state* state_dev, int32_t* err_flag_dev, void* stream) {
@@ -1435,16 +1374,6 @@ int effq_project_dual_next(const float* v, const float* wstar, const effq_fp_sta
 int effq_admm_project_dual(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
                            float* dual, float dual_div, int8_t* Gq_out, size_t n, void* stream) {
   return effq_project_dual_checked(v, wstar, state_dev, levels, G, dual, dual_div, Gq_out, n, nullptr, stream);
-}
-
-int effq_admm_keep_best(const double* sqerr_dev, double* best_dev, int iter, const float* G, const float* b,
-                        float* best_G, float* best_b, size_t nw, size_t nb, void* stream) {
-  EFFQ_CHECK_ARG(sqerr_dev && best_dev && G && best_G && iter >= 0);
-  EFFQ_CHECK_ARG((b == nullptr) == (best_b == nullptr));
-  hipLaunchKernelGGL(k_keep_best, dim3(stream_grid(nw)), dim3(TPB), 0, as_stream(stream), sqerr_dev, best_dev, iter,
-                     G, b, best_G, best_b, nw, nb);
-  EFFQ_LAUNCH_CHECK();
-  return EFFQ_OK;
 }
 
 int effq_act_quant_backward(const float* x, const float* alpha_dev, int levels, const float* gq, float* gx_out,

@@ -950,41 +950,4 @@ int effq_project_dual_checked(const float* v, const float* wstar, const effq_fp_
                               float* dual, float dual_div, int8_t* Gq_out, size_t n, int32_t* err_flag_dev,
                               void* stream);   // quant_reduce.hip (internal to the library)
 
-int effq_fixed_point_coop_light(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
-                                double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream);   // internal
-
-int effq_admm_chain_step(const effq_chain_args* a, void* stream) {
-  EFFQ_CHECK_ARG(a != nullptr && a->state != nullptr && a->err_flag != nullptr && a->v != nullptr && a->G != nullptr);
-  const size_t nw = (size_t)a->c2 * (size_t)(a->n - (a->has_bias ? 1 : 0));
-  if (nw > effq_fp_coop_max()) {
-    set_error("admm_chain_step: %zu weights exceed the single-launch fixed points", nw);
-    return EFFQ_ERR_ARG;
-  }
-  int rc;
-  if (a->shift_terms > 0)
-    rc = effq_prox_solve_shifted(a->B0, a->Ainv, a->W0, a->b0, a->G_prev, a->dual, a->c2, a->n, a->has_bias, a->rho,
-                                 a->eta, a->rho_inv, a->shift_terms, a->wstar, a->bstar, a->prox_ws, a->prox_ws_bytes,
-                                 stream);
-  else
-    rc = effq_prox_solve(a->B0, a->Ainv, a->W0, a->b0, a->G_prev, a->dual, a->c2, a->n, a->has_bias, a->rho, a->eta,
-                         a->wstar, a->bstar, a->prox_ws, a->prox_ws_bytes, stream);
-  if (rc != EFFQ_OK) return rc;
-  static const int light_lo = getenv("EFFQ_FP_LIGHT_MIN") ? atoi(getenv("EFFQ_FP_LIGHT_MIN")) : 8192;   // tuning aid
-  static const int light_hi = getenv("EFFQ_FP_LIGHT_MAX") ? atoi(getenv("EFFQ_FP_LIGHT_MAX")) : 131072;   // tuning aid
-  if (nw > (size_t)light_lo && nw <= (size_t)light_hi)
-    // mid-size tensors (the 32- and 64-channel 3^3 layers): small-footprint cooperative variant that co-resides with
-    // the overlapped loss conv (quant_reduce.hip)
-    rc = effq_fixed_point_coop_light(a->wstar, a->dual, a->v, nw, a->levels, -1.0, 1.0, a->tol, a->max_iter, a->state,
-                                     a->red_ws, stream);
-  else if (nw <= effq_fp_small_max())
-    rc = effq_fixed_point_small(a->wstar, a->dual, a->v, nw, a->levels, -1.0, 1.0, a->tol, a->max_iter, a->state, stream);
-  else
-    rc = effq_fixed_point_coop(a->wstar, a->dual, a->v, nw, a->levels, -1.0, 1.0, a->tol, a->max_iter, a->state,
-                               a->red_ws, stream);
-  if (rc != EFFQ_OK) return rc;
-  // the convergence check rides in the projection kernel (one launch less than effq_fp_check + project_dual)
-  return effq_project_dual_checked(a->v, a->wstar, a->state, a->levels, a->G, a->dual, a->dual_div, a->Gq, nw,
-                                   a->err_flag, stream);
-}
-
 }  // extern "C"

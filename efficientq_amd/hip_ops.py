@@ -462,32 +462,6 @@ class HipOps:
                                                _ptr(bstar), _ptr(ws), ws.numel(), self.stream),
               "effq_prox_solve_shifted")
 
-    # -- one ADMM chain step per binding call ------------------------------------------------------
-    def chain_supported(self, n_weights: int) -> bool:
-        return n_weights <= self.lib.effq_fp_coop_max() and COOP_FIXED_POINT
-
-    def new_chain(self, B0, W0, b0, dual, wstar, v, err_flag, levels: int, eta: float):
-        """Argument block of effq_admm_chain_step for one layer; the per-iteration fields are set by chain_step."""
-        c2, n = B0.shape
-        a = _lib.ChainArgs()
-        ws = self._workspace("prox", self.lib.effq_prox_ws_bytes(c2, n))
-        a.B0, a.W0, a.b0 = B0.data_ptr(), W0.data_ptr(), (b0.data_ptr() if b0 is not None else None)
-        a.dual, a.wstar, a.v = dual.data_ptr(), wstar.data_ptr(), v.data_ptr()
-        a.err_flag = err_flag.data_ptr()
-        a.prox_ws, a.prox_ws_bytes, a.red_ws = ws.data_ptr(), ws.numel(), self._red_ws.data_ptr()
-        a.c2, a.n, a.has_bias, a.levels = c2, n, int(b0 is not None), int(levels)
-        a.max_iter, a.tol, a.eta = 100 * int(levels), ADMM_TOL, float(eta)
-        a._keep = (B0, W0, b0, dual, wstar, v, err_flag, ws)      # the block holds raw pointers
-        return a
-
-    def chain_step(self, a, Ainv, G_prev, bstar, G, Gq, state, rho: float, dual_div: float, rho_inv: float = 0.0,
-                   shift_terms: int = 0):
-        a.Ainv, a.G_prev = Ainv.data_ptr(), G_prev.data_ptr()
-        a.bstar = bstar.data_ptr() if bstar is not None else None
-        a.G, a.Gq, a.state = G.data_ptr(), (Gq.data_ptr() if Gq is not None else None), state.data_ptr()
-        a.rho, a.rho_inv, a.shift_terms, a.dual_div = float(rho), float(rho_inv), int(shift_terms), float(dual_div)
-        check(self.lib.effq_admm_chain_step(C.byref(a), self.stream), "effq_admm_chain_step")
-
     # -- the whole ADMM loop of a layer in one binding call ---------------------------------------------
     def admm_run(self, A0, B0, W0, b0, geom: Geom, y_ndhwc, *, xq=None, xidx=None, act_alpha=None, act_levels: int = 0,
                  loss_kind: int = 0, rho: float, rho_max: float, eta: float, iters: int, period: int, levels: int,
@@ -649,23 +623,6 @@ class HipOps:
                                             _ptr(ws), ws.numel(), self.stream), "conv3d_calib_step_i8")
         return sqerr
 
-    def conv_step_i8_pair(self, xidx, Gq2, bias2, geom: Geom, y_ndhwc, act_alpha, act_levels: int, w_state2,
-                          w_levels: int, sqerr2):
-        """Exact-integer loss of TWO iterates in one pass over x and y (conv3d_calib_step_i8_pair).  Gq2, bias2,
-        w_state2, sqerr2: pairs of tensors (bias2 entries may both be None)."""
-        if xidx.dtype != torch.uint8 or any(t.dtype != torch.int8 for t in Gq2):
-            raise _lib.EffqError("conv_step_i8_pair wants uint8 level ids and int8 weight numerators")
-        for q, b in zip(Gq2, bias2):
-            _check_shapes(geom, xidx, q, b, y_ndhwc)
-        al = self._f32(act_alpha.reshape(1))
-        ws = self._workspace("conv_i8", self.lib.effq_conv_i8_ws_bytes(C.byref(geom)))
-        arr = lambda ts: (C.c_void_p * 2)(*[None if t is None else t.data_ptr() for t in ts])
-        check(self.lib.conv3d_calib_step_i8_pair(_ptr(xidx), arr(Gq2), arr(bias2), _ptr(self._f32(y_ndhwc)),
-                                                 C.byref(geom), _ptr(al), int(act_levels), arr(w_state2), int(w_levels),
-                                                 arr(sqerr2), _ptr(ws), ws.numel(), self.stream),
-              "conv3d_calib_step_i8_pair")
-        return sqerr2
-
     # -- f3: gradients of the activation quantiser, Adam ----------------------------------------------------
     def act_quant_backward(self, x: torch.Tensor, alpha: torch.Tensor, levels: int, gq: torch.Tensor, want_gx=True):
         """(gx, galpha[device double]) of q = discretize(x/alpha, L, 0, 1)*alpha given gq (effq_act_quant_backward)."""
@@ -681,13 +638,6 @@ class HipOps:
         """torch.optim.Adam step in place on flat fp32 tensors (effq_adam_step)."""
         check(self.lib.effq_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), lr, b1, b2, eps, int(t), p.numel(),
                                       self.stream), "effq_adam_step")
-
-    def admm_keep_best(self, sqerr, best, it: int, G, b, best_G, best_b):
-        if best.numel() < 4:
-            raise _lib.EffqError("admm_keep_best: best_dev holds 4 doubles (loss, iteration, ticket, spare)")
-        check(self.lib.effq_admm_keep_best(_ptr(sqerr), _ptr(best), it, _ptr(G), _ptr(b), _ptr(best_G), _ptr(best_b),
-                                           G.numel(), 0 if b is None else b.numel(), self.stream),
-              "effq_admm_keep_best")
 
     # -- the conv ---------------------------------------------------------------------------------
     def conv_step(self, x_ndhwc: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], geom: Geom,

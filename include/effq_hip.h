@@ -244,12 +244,6 @@ int effq_admm_project_dual(const float* v, const float* wstar, const effq_fp_sta
                            float* G, float* dual, float dual_div, int8_t* Gq_out, size_t n, void* stream);
 /* Gq_out (optional, levels <= 128): signed level numerators j' = 2*level-(L-1), so that G = alpha_w*j'/(L-1);
  * the operand of the exact-integer conv below. */
-/* Best-iterate bookkeeping on the device: if (iter==0 || loss<best_loss) copy G,b into best_G,best_b.
- * loss_dev = {sum sq err (double)}; best_dev = FOUR doubles, zero-initialised by the caller: {best loss, best iter
- * (as double), ticket word of the kernel, spare}. */
-int effq_admm_keep_best(const double* sqerr_dev, double* best_dev, int iter, const float* G, const float* b,
-                        float* best_G, float* best_b, size_t nw, size_t nb, void* stream);
-
 /* ---- the entry point north_star names ------------------------------------------------
  * One ADMM iteration's device work (EfficientQConv.py:118-122,161-165; PTQConv.py:154-167):
  * out = conv3d(xq, G, bias) in fp32 on the matrix cores (f32 MFMA, exact fp32 fma chains),
@@ -278,16 +272,6 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
                          const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, void* ws,
                          size_t ws_bytes, void* stream);
 
-/* TWO iterates in one pass (32 -> 32 channels: that layer shape is bound by the stream of targets, and the loss of an
- * iterate is only needed when the best one is picked after the loop): Gq[2], bias[2] (both NULL or both given),
- * w_state_dev[2], sqerr_out[2] are host arrays of two device pointers.  Each result is bit-identical to the single
- * call.  ws: effq_conv_i8_ws_bytes(geom) (it covers both forms). */
-int effq_conv_i8_pair_supported(const effq_geom* g, int act_levels, int w_levels);
-int conv3d_calib_step_i8_pair(const uint8_t* xidx_ndhwc, const int8_t* const* Gq, const float* const* bias,
-                              const float* y_fp, const effq_geom* g, const float* act_alpha_dev, int act_levels,
-                              const effq_fp_state* const* w_state_dev, int w_levels, double* const* sqerr_out, void* ws,
-                              size_t ws_bytes, void* stream);
-
 /* The same exact-integer loss for the layers the tiled kernels above do not take: few taps*channels
  * (KD*KH*KW*C1 <= 256 with C1 == 4 or C1 % 16 == 0: the first conv, the 1x1x1 convs, the classifier), any
  * stride/padding, and up to 256 levels on either side (q_first/q_last = 256 in the reference's recipes).
@@ -312,26 +296,6 @@ int effq_act_quant_backward(const float* x, const float* alpha_dev, int levels, 
 /* torch.optim.Adam step (no weight decay, no amsgrad) on n parameters; t = step number starting at 1. */
 int effq_adam_step(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
                    int t, size_t n, void* stream);
-
-/* ---- one ADMM chain step in ONE call (EfficientQConv.py:104-111,129-137) --------------------------
- * prox solve -> v = w* + dual and its scale fixed point -> convergence check -> projection + dual update, issued
- * back to back on `stream`: exactly effq_prox_solve[_shifted] + effq_fixed_point_small/coop + effq_fp_check +
- * effq_admm_project_dual with the same arguments.  It exists for the host: the small layers of a network are
- * bound by the ~7 binding calls per iteration, not by the GPU.  shift_terms > 0 selects the shifted solve
- * (Ainv = A(rho_inv)^-1).  Returns EFFQ_ERR_ARG when the weight tensor is too large for the single-launch
- * fixed points (caller falls back to the separate entry points). */
-typedef struct effq_chain_args {
-  const float* B0; const float* Ainv; const float* W0; const float* b0;   /* b0 NULL when !has_bias */
-  const float* G_prev;          /* G of the previous iteration */
-  float* dual; float* wstar; float* bstar; float* v;
-  float* G; int8_t* Gq;         /* outputs of the projection (Gq may be NULL) */
-  effq_fp_state* state; int32_t* err_flag;
-  void* prox_ws; size_t prox_ws_bytes; void* red_ws;
-  int32_t c2, n, has_bias, levels, shift_terms, max_iter;
-  double rho, eta, rho_inv, tol;
-  float dual_div;
-} effq_chain_args;
-int effq_admm_chain_step(const effq_chain_args* a, void* stream);
 
 /* ---- the whole ADMM loop of a layer in ONE call (EfficientQConv.py:99-144) -----------------------------------
  * Enqueues `iters` iterations of { prox solve, weight-scale fixed point, projection + dual update } on stream_main,

@@ -25,11 +25,8 @@ Gq = torch.empty(w.shape, dtype=torch.int8, device=dev)
 st_w = ops.new_fp_state()
 ops.weight_fixed_point(w, dual, v, 4, st_w)
 ops.admm_project_dual(v, w, st_w, 4, G, dual, 1.0, Gq)
-Gq2 = [Gq, Gq.clone()]; st2 = [st_w, st_w.clone()]; sq2 = [sq, sq.clone()]
 def step():
-    if mode == "i8_32p":
-        ops.conv_step_i8_pair(xidx, Gq2, [b, b], geom, y, alpha, 4, st2, 4, sq2)
-    elif mode.startswith("i8"):
+    if mode.startswith("i8"):
         ops.conv_step_i8(xidx, Gq, b, geom, y, alpha, 4, st_w, 4, sq)
     else:
         ops.conv_step(xq, G, b, geom, y, None, sqerr=sq)

@@ -175,15 +175,6 @@ class OracleOps:
     def admm_read(run, best):
         return dict(hist=run.hist[:, 0].tolist(), best=best.tolist(), alpha_w=run.alpha_w, w_iters=run.w_iters, err=0)
 
-    def admm_keep_best(self, sqerr, best, it, G, b, best_G, best_b):
-        if it == 0 or sqerr[0].item() < best[0].item():
-            best_G.copy_(G)
-            if b is not None:
-                best_b.copy_(b)
-            best[0] = sqerr[0]
-            best[1] = float(it)
-
-    # conv
     def conv_step(self, x_ndhwc, weight, bias, geom, y_ndhwc=None, att=None, act_alpha=None, act_levels=0,
                   want_out=False, sqerr=None):
         x = _ncdhw(x_ndhwc)

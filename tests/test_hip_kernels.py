@@ -574,55 +574,6 @@ def test_fp64_gram_system_rejects_what_it_cannot_do(ops):
     assert not ops.gram_f64_supported(make_geom((1, 4, 8, 8, 8), 128, 1, 1, 0), True)      # c2 > 64
 
 
-@pytest.mark.parametrize("sp,La,Lw,with_bias", [((16, 8, 8), 4, 4, True), ((5, 6, 9), 4, 4, True), ((17, 4, 8), 16, 16, False),
-                                                  ((33, 7, 10), 4, 4, True)])
-def test_paired_exact_int_conv_equals_two_single_passes(ops, sp, La, Lw, with_bias):
-    """conv3d_calib_step_i8_pair: the losses of two iterates from ONE pass over x and y (32 -> 32 channels) equal two
-    single passes (same integer sums per iterate; the squared errors are added in another order, and the single-pass
-    kernel for tile-divisible volumes adds them in fp32 within a tile: compared to 1e-6) and the fp64 value of the
-    integer model to 1e-6; ragged volumes included (extent not a multiple of the 16 x 4 x 8 tile)."""
-    from efficientq_amd.hip_ops import make_geom
-    gen = torch.Generator().manual_seed(sum(sp) + La)
-    N, c = 2, 32
-    x = torch.relu(torch.randn(N, *sp, c, generator=gen))
-    geom = make_geom((N, c, *sp), c, 3, 1, 1)
-    assert ops.lib.effq_conv_i8_pair_supported(geom, La, Lw)
-    a_act, _, st_a = ops.fit_scale(dev(x), La, 0.0, 1.0)
-    _, _, xidx = ops.quant_dequant_f64path(dev(x), st_a, La, 0.0, 1.0, want_idx=True)
-    alpha_act = torch.tensor(a_act, dtype=torch.float32, device="cuda:0")
-    y = dev(torch.randn(N, *sp, c, generator=gen))
-    Gqs, sts, bs = [], [], []
-    for it in range(2):
-        wst = dev(torch.randn(c, c, 3, 3, 3, generator=gen) * (0.05 + 0.02 * it))
-        dual, v, G = torch.zeros_like(wst), torch.empty_like(wst), torch.empty_like(wst)
-        st_w = ops.new_fp_state()
-        ops.weight_fixed_point(wst, dual, v, Lw, st_w)
-        Gq = torch.empty(wst.shape, dtype=torch.int8, device="cuda:0")
-        ops.admm_project_dual(v, wst, st_w, Lw, G, dual, 1.0, Gq)
-        Gqs.append(Gq)
-        sts.append(st_w)
-        bs.append(dev(torch.randn(c, generator=gen) * 0.1) if with_bias else None)
-    single = []
-    for it in range(2):
-        sq = torch.zeros(2, dtype=torch.float64, device="cuda:0")
-        ops.conv_step_i8(xidx, Gqs[it], bs[it], geom, y, alpha_act, La, sts[it], Lw, sq)
-        single.append(sq.cpu().tolist())
-    sq2 = [torch.zeros(2, dtype=torch.float64, device="cuda:0") for _ in range(2)]
-    ops.conv_step_i8_pair(xidx, Gqs, bs, geom, y, alpha_act, La, sts, Lw, sq2)
-    for it in range(2):
-        got = sq2[it].cpu().tolist()
-        assert got[0] == got[1]
-        assert abs(got[0] - single[it][0]) <= 1e-6 * single[it][0], (it, got, single[it])
-        out = torch.nn.functional.conv3d(xidx.cpu().permute(0, 4, 1, 2, 3).double(), Gqs[it].cpu().double(), None, 1, 1)
-        sc = float(np.float32(a_act)) * float(np.float32(ops.read_fp_state(sts[it])[0])) / ((La - 1) * (Lw - 1))
-        bb = bs[it].cpu().double().view(1, -1, 1, 1, 1) if with_bias else 0.0
-        ref = ((out * sc + bb - y.cpu().permute(0, 4, 1, 2, 3).double()) ** 2).sum().item()
-        assert abs(got[0] - ref) <= 1e-6 * ref
-    again = [torch.zeros(2, dtype=torch.float64, device="cuda:0") for _ in range(2)]
-    ops.conv_step_i8_pair(xidx, Gqs, bs, geom, y, alpha_act, La, sts, Lw, again)
-    assert [t.cpu().tolist() for t in again] == [t.cpu().tolist() for t in sq2]          # deterministic
-
-
 @pytest.mark.parametrize("c1,c2,k,s,p,La,Lw,sp", [
     (4, 32, 3, 2, 1, 256, 256, (12, 10, 14)),     # the first conv of the BraTS net (q_first = 256)
     (32, 3, 1, 1, 0, 256, 256, (6, 7, 9)),        # the classifier (q_last = 256)
@@ -934,56 +885,6 @@ def test_bit_packed_level_storage_round_trip(ops, bits, levels, n):
         want[(i * bits) // 8] |= np.uint8((int(v) << ((i * bits) % 8)) & 0xFF)
     assert np.array_equal(packed.cpu().numpy(), want)
     assert torch.equal(ops.unpack_levels(packed, n, bits).cpu(), idx)
-
-
-@pytest.mark.parametrize("c2,c1k,L,shift", [(32, 864, 4, False), (16, 108, 256, False), (64, 64, 16, True), (128, 3456, 4, False)])
-def test_chain_step_equals_the_separate_entry_points(ops, c2, c1k, L, shift):
-    """effq_admm_chain_step = effq_prox_solve[_shifted] + effq_fixed_point_small/coop + effq_fp_check +
-    effq_admm_project_dual issued from one binding call: bit-identical outputs."""
-    gen = torch.Generator().manual_seed(c2 + c1k + L)
-    n = c1k + 1
-    X = torch.randn(n, 2 * n, generator=gen)
-    A0 = dev((2 * X @ X.T).float())
-    rho, eta = 20.0, 1.0
-    Ainv = ops.spd_inverse(A0, True, 2 * rho if shift else rho, eta)
-    B0 = dev(torch.randn(c2, n, generator=gen) * 5)
-    W0 = dev(torch.randn(c2, c1k, generator=gen) * 0.1)
-    b0 = dev(torch.randn(c2, generator=gen) * 0.1)
-    Gp = dev(torch.randn(c2, c1k, generator=gen) * 0.1)
-    dual0 = dev(torch.randn(c2, c1k, generator=gen) * 0.01)
-    outs = []
-    for fused in (False, True):
-        dual = dual0.clone()
-        wstar, v, G = torch.empty_like(W0), torch.empty_like(W0), torch.empty_like(W0)
-        bstar = torch.empty(c2, device="cuda:0")
-        Gq = torch.empty(W0.shape, dtype=torch.int8, device="cuda:0")
-        st = ops.new_fp_state()
-        err = torch.zeros(1, dtype=torch.int32, device="cuda:0")
-        if fused:
-            ch = ops.new_chain(B0, W0, b0, dual, wstar, v, err, L, eta)
-            if shift:
-                ops.chain_step(ch, Ainv, Gp, bstar, G, Gq, st, rho, 2.0, 2 * rho, ops.shift_terms(rho, eta, 2 * rho))
-            else:
-                ops.chain_step(ch, Ainv, Gp, bstar, G, Gq, st, rho, 2.0)
-        else:
-            if shift:
-                ops.prox_solve_shifted(B0, Ainv, W0, b0, Gp, dual, rho, eta, 2 * rho, wstar, bstar)
-            else:
-                ops.prox_solve(B0, Ainv, W0, b0, Gp, dual, rho, eta, wstar, bstar)
-            assert ops.weight_fixed_point(wstar, dual, v, L, st) is None
-            ops.fp_check(st, err)
-            ops.admm_project_dual(v, wstar, st, L, G, dual, 2.0, Gq)
-        assert err.item() == 0
-        outs.append((wstar.cpu(), bstar.cpu(), v.cpu(), G.cpu(), Gq.cpu(), dual.cpu(), ops.read_fp_state(st)))
-    for a, b in zip(outs[0][:-1], outs[1][:-1]):
-        assert torch.equal(a, b)
-    if 8192 < c2 * c1k <= 131072:
-        # mid-size tensors: the chain step runs the small-footprint cooperative fixed point (it co-resides with the
-        # overlapped loss conv), the separate call the single-workgroup one - another summation order for alpha
-        (a0, i0, d0), (a1, i1, d1) = outs[0][-1], outs[1][-1]
-        assert i0 == i1 and d0 == d1 and abs(a0 - a1) <= 1e-13 * abs(a0)
-    else:
-        assert outs[0][-1] == outs[1][-1]
 
 
 @pytest.mark.parametrize("C,sp,scale", [(32, (4, 6, 5), (2, 2, 2)), (3, (5, 4, 7), (2, 2, 2)), (64, (3, 3, 4), (2, 2, 1)),

@@ -592,8 +592,9 @@ def test_cli_ptq_mission_writes_reference_artifacts(tmp_path):
 
 
 def test_mixed_precision_search_respects_budget_and_improves_with_bits():
-    """Row f4 harness on the tiny net: the greedy assignment stays within the bit budget, uses only the
-    candidate levels, and more bits never make the calibrated network worse (sum of layer losses)."""
+    """Row f4 harness on the tiny net (cheap layer_loss sensitivities): the greedy assignment stays within the bit
+    budget, uses only the candidate levels, and more bits make the calibrated network better end to end (relative MSE of
+    the quantised output against the FP output)."""
     from efficientq_amd import calibrate as K, config as Cf, mixed, synth
     args = Cf.make_args(dict(Cf.TINY_NET, width="8,16,8"), 4, 4)
     QConv, _, kwQ = Cf.get_conv_class(args)
@@ -604,14 +605,51 @@ def test_mixed_precision_search_respects_budget_and_improves_with_bits():
         m.eval(); K.search_fold_and_remove_bn(m); m.to(DEV); K.set_name(m)
         return m
     vols = torch.randn(2, 1, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(DEV)
-    res = mixed.search(build, vols, "lits", args.init_stride, [2.0, 3.0, 4.0], levels=(4, 8, 16))
+    res = mixed.search(build, vols, "lits", args.init_stride, [2.0, 3.0, 4.0], levels=(4, 8, 16),
+                       sensitivity="layer_loss")
     assert [r["budget_bits"] for r in res] == [2.0, 3.0, 4.0]
     for r in res:
         assert r["avg_bits"] <= r["budget_bits"] + 1e-9
         assert set(r["levels"].values()) <= {4, 8, 16} and len(r["levels"]) == 8
     assert set(res[0]["levels"].values()) == {4} and set(res[2]["levels"].values()) == {16}
-    assert res[2]["sum_layer_loss"] < res[0]["sum_layer_loss"]
-    assert res[1]["sum_layer_loss"] <= res[0]["sum_layer_loss"] * 1.02
+    assert res[2]["output_error"] < res[1]["output_error"] < res[0]["output_error"]
+
+
+def test_mixed_precision_search_on_the_brats_net():
+    """BASELINE configs[4] on its real net (BraTS 3D-UNet, 20 searched layers, 2 volumes of 4 x 64^3; one GPU of the 8 the
+    config names: budgets are independent replicas).  End-to-end sensitivities (41 calibrations), then for each budget:
+    the average stays within it, only candidate levels are used, 2 / 4 bits reproduce the uniform maps, and the CHOSEN
+    map at 2.5 and 3 bits is at least 10 % better end to end than the uniform map of the next-lower uniform budget (2 bits)
+    - the search spends extra bits where they help; observed: the 2.5-bit map already reaches the uniform 4-bit error,
+    because the 4-level ACTIVATIONS set the floor - and beyond that the error stays on its plateau (within 5 %: two
+    calibrations of equally good maps differ by up to 3 % there)."""
+    from efficientq_amd import calibrate as K, config as Cf, mixed, synth
+    args = Cf.make_args(Cf.BRATS_NET, 4, 4)
+    QConv, _, kwQ = Cf.get_conv_class(args)
+
+    def build():
+        m = Cf.get_model_cube(args, QConv, kwQ)[0]["model"]
+        synth.randomise_network(m, 0)
+        m.eval(); K.search_fold_and_remove_bn(m); m.to(DEV); K.set_name(m)
+        return m
+    vols = synth.calib_batch("brats", range(2), 64).to(DEV)
+    budgets = [2.0, 2.5, 3.0, 4.0]
+    res = mixed.search(build, vols, "brats", args.init_stride, budgets, levels=(4, 8, 16))
+    u4 = mixed.uniform(build, vols, "brats", args.init_stride, 4)
+    u16 = mixed.uniform(build, vols, "brats", args.init_stride, 16)
+    print([(r["budget_bits"], round(r["avg_bits"], 3), r["output_error"], r["agreement"]) for r in res], u4, u16)
+    for r, b in zip(res, budgets):
+        assert r["budget_bits"] == b and r["avg_bits"] <= b + 1e-9
+        assert set(r["levels"].values()) <= {4, 8, 16} and len(r["levels"]) == 20
+    assert set(res[0]["levels"].values()) == {4} and set(res[3]["levels"].values()) == {16}
+    # same maps => same calibration (deterministic): the uniform runs are reproduced
+    assert abs(res[0]["output_error"] - u4["output_error"]) <= 1e-6 * u4["output_error"]
+    assert abs(res[3]["output_error"] - u16["output_error"]) <= 1e-6 * u16["output_error"]
+    assert res[1]["avg_bits"] > 2.2 and res[2]["avg_bits"] > 2.7          # the budget is spent
+    assert res[1]["output_error"] < 0.9 * u4["output_error"] and res[2]["output_error"] < 0.9 * u4["output_error"]
+    assert res[2]["output_error"] <= 1.05 * res[1]["output_error"]
+    assert res[3]["output_error"] <= 1.05 * res[2]["output_error"]
+    assert res[3]["agreement"] >= res[0]["agreement"] - 1e-3
 
 
 def test_packed_weight_export_round_trip():
