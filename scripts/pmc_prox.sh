@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over the prox solve (scripts/prof_prox.py): counters of the 256-row GEMM kernel, one pass per group.
-# usage (on the GPU box, from the repo root): bash scripts/pmc_prox.sh OUTDIR
-OUT=$1; KSUB="k_prox_gemm<2, 4, 1, 2>"
+# usage (on the GPU box, from the repo root): bash scripts/pmc_prox.sh OUTDIR [KERNEL_SUBSTR]
+OUT=$1; KSUB=${2:-"k_prox_gemm_b3<256, 256, 4, 2>"}
 mkdir -p $OUT; rm -f $OUT/summary.txt
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp

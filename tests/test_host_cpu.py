@@ -263,6 +263,47 @@ def test_data_parallel_two_ranks_gloo_matches_single_rank(tmp_path):
     assert np.all(np.abs(a - b) <= 1e-3 * b), (a, b)
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="needs the reference checkout (build container only)")
+def test_reference_side_registration_shim_satisfies_the_reference_orchestrator():
+    """the two-line class a maintainer adds to the reference tree - the HIP calibrator with the
+    reference's own PTQConv as a second base - is what makes the reference's ptqer helpers (isinstance(module, (PTQConv,
+    PTQBlock)), ptqer.py:17-80) see the layers.  Built here against the REAL reference classes (in a child process: the
+    reference's package names must not leak into this test session): construction through the product's UResQ factory,
+    MRO, the reference's mode / name / mask broadcasters, state_dict keys."""
+    code = r'''
+import sys, types
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference/src")
+nib = types.ModuleType("nibabel")
+nib.Nifti1Image, nib.load = (lambda *a, **k: None), (lambda f: None)
+sys.modules["nibabel"] = nib                       # the one dependency of ptqer that this image lacks (SURVEY appendix A)
+from models.PTQConv import PTQConv as RefPTQConv
+import ptqer
+sys.path.insert(0, sys.argv[1])
+from efficientq_amd.qconv import EfficientQConvHIP as Hip
+from efficientq_amd import config as Cf
+class EfficientQConvHIP(Hip, RefPTQConv):          # the shim of INTEGRATION.md
+    pass
+assert [c.__module__.split(".")[0] for c in EfficientQConvHIP.__mro__[1:4]] == ["efficientq_amd", "efficientq_amd", "models"]
+args = Cf.make_args(Cf.TINY_NET, 4, 4)
+_, _, kwQ = Cf.get_conv_class(args)
+model = Cf.get_model_cube(args, EfficientQConvHIP, kwQ)[0]["model"]
+q = [m for m in model.modules() if isinstance(m, RefPTQConv)]
+assert len(q) == 10 and all(isinstance(m, Hip) for m in q)
+ptqer.set_name(model); ptqer.set_mask(model, ["m"]); ptqer.set_quantizing(model)
+assert q[0].name == "conv0.conv" and q[0].mask_pyramid == ["m"] and q[0]._quantizing and not q[0]._fp
+ptqer.set_quantized(model)
+assert all(m._quantized for m in q)
+keys = set(model.state_dict())
+assert {"conv0.conv.weight", "conv0.conv.alpha_act", "conv0.conv.alpha_w"} <= keys
+assert type(q[0]).ptq is Hip.ptq                   # the HIP calibrator, not the reference's NotImplementedError
+print("ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def _bench(*flags, env=None, timeout=600):
     e = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
     e.pop("WORLD_SIZE", None)
