@@ -250,7 +250,7 @@ class OpTimer:
 
     def summary(self, steps):
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
         except (OSError, ValueError):
             traffic = {}
         rows = []

@@ -269,19 +269,38 @@ __global__ __launch_bounds__(256) void k_gj_trail_sym(double* __restrict__ A, in
     As[r * LDA_S + c] = NZ[(size_t)(ib * NBK + r) * NBK + c];      // -Z_i
   }
   lds_barrier();
-  for (int t = 0; t < GJ_CT; ++t) {
+  // The strip's tiles in turn, the C tile of the NEXT one fetched into a second register set before the MFMAs of the
+  // current one (the update moves 64 KB per 0.5 MFLOP tile: it is bound by memory latency, not by the matrix cores)
+  auto live = [&](int t) -> bool {
     const int jb = blockIdx.x * GJ_CT + t;
-    if (jb >= nblk || jb == kblk || jb < ib) continue;
-    if (ahead && ib == kn && jb == kn) continue;                   // the look-ahead workgroup owns the next pivot block
-    double* Cb = A + (size_t)(ib * NBK + wr * 32) * npad + (size_t)jb * NBK + wc * 32;
-    const double* Rb = XT + (size_t)jb * NBK + wc * 32;
-    f64x4 acc[2][2];
+    return t < GJ_CT && jb < nblk && jb != kblk && jb >= ib && !(ahead && ib == kn && jb == kn);
+  };
+  auto fetch = [&](int t, f64x4 (&c)[2][2]) {
+    const int jb = blockIdx.x * GJ_CT + t;
+    const double* Cb = A + (size_t)(ib * NBK + wr * 32) * npad + (size_t)jb * NBK + wc * 32;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = Cb[(size_t)(mi * 16 + lk + 4 * r) * npad + ni * 16 + lr];
+        for (int r = 0; r < 4; ++r) c[mi][ni][r] = Cb[(size_t)(mi * 16 + lk + 4 * r) * npad + ni * 16 + lr];
+  };
+  f64x4 nxt[2][2];
+  int t = 0;
+  while (t < GJ_CT && !live(t)) ++t;
+  if (t < GJ_CT) fetch(t, nxt);
+  while (t < GJ_CT) {
+    const int jb = blockIdx.x * GJ_CT + t;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = nxt[mi][ni];
+    int tn = t + 1;
+    while (tn < GJ_CT && !live(tn)) ++tn;
+    if (tn < GJ_CT) fetch(tn, nxt);
+    double* Cb = A + (size_t)(ib * NBK + wr * 32) * npad + (size_t)jb * NBK + wc * 32;
+    const double* Rb = XT + (size_t)jb * NBK + wc * 32;
 #pragma unroll 4
     for (int ks = 0; ks < NBK / 4; ++ks) {
       double a[2], b[2];
@@ -300,6 +319,7 @@ __global__ __launch_bounds__(256) void k_gj_trail_sym(double* __restrict__ A, in
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Cb[(size_t)(mi * 16 + lk + 4 * r) * npad + ni * 16 + lr] = acc[mi][ni][r];
+    t = tn;
   }
 }
 
