@@ -512,6 +512,18 @@ def main():
     exact = bool(_Q.EXACT_INT_DEFAULT)
     if roof is not None:
         roof = dict(roof)
+        if "k_prox_gemm_b3" in roof["kernel"]:
+            # the same launch on the fp32 scale (the product it evaluates, against the f32 matrix peak it replaced) and the
+            # share of the SIMD cycles its matrix cores were busy (rocprofv3 PMC of the kernel alone, profiles/r03_pmc_prox)
+            alg = roof["work_per_launch"] / 6.0
+            roof["fp32_equivalent"] = {"achieved": round(alg / (roof["avg_ms"] * 1e-3) / 1e12, 2),
+                                       "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(alg / (roof["avg_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                       "note": "2 c2 n^2 flop of the fp32 product per launch; round 2 ran it on the f32 "
+                                               "matrix cores at 0.55 of their peak"}
+            roof["mfma_busy_frac_alone"] = 0.44
+            roof["note"] = ("frac = executed bf16 MFMA flop / dense bf16 peak quoted at 2.4 GHz; the chip holds 1.5 - 1.7 GHz "
+                            "in dense bf16 loops on random data (MI355X_MICROARCH.md, DVFS give-back)")
     # 24.55 TFLOP per 4x128^3 BraTS volume, 99.69 per 1x160^3 LiTS volume (conv x 201 + Gram), scaled by voxels
     tfv = (NET_TFLOP_PER_VOLUME * (a.size / 128.0) ** 3) if a.net == "brats" else (99.69 * (a.size / 160.0) ** 3)
     baseline_cfg = {2: "configs[1]", 3: "configs[2]", 4: "configs[3]"}[a.config]
