@@ -72,6 +72,29 @@ def test_config2_brats_net_4_levels_first_layer_vs_oracle():
     print(f"config 2 geometry: first layer_loss hip {losses[0]:.6e} oracle {want.layer_loss:.6e}; FP-vs-Q agreement {agree:.4f}")
 
 
+def test_config2_at_its_stated_size_is_deterministic():
+    """configs[1] as BASELINE.json states it: 16 volumes of 4x128^3 on one GPU, 4/4 levels - the workload of the bench
+    line.  Two calibrations of the same pristine network must agree BIT FOR BIT (every reduction of the path is
+    order-fixed: integer Gram sums, per-workgroup partial slabs added in workgroup order, fixed DPP trees, the best
+    iterate picked from a complete history) - which is also what keeps data-parallel replicas in lock step."""
+    from efficientq_amd import calibrate as K, config as Cf, synth
+    args, model = _build(Cf.BRATS_NET, 4)
+    pristine = {k: v.clone() for k, v in model.state_dict().items()}
+    vols = synth.calib_batch("brats", range(16), 128).to(DEV)
+    model.to(DEV)
+    runs = []
+    for _ in range(2):
+        model.load_state_dict({k: v.to(DEV) for k, v in pristine.items()}, strict=True)
+        res = K.calibrate_model(model, vols, "brats", args.init_stride)
+        losses, agree = _check_calibrated(model, res, 22, "brats", 0.98)
+        runs.append((losses, agree, {k: v.clone() for k, v in model.state_dict().items()}, res["output_q"][-1].clone()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
+    assert torch.equal(runs[0][3], runs[1][3])
+    print(f"config 2 at 16 volumes: FP-vs-Q agreement {runs[0][1]:.4f}, sum layer_loss {runs[0][0].sum():.4f}")
+
+
 def test_fp_targets_are_snapshots_taken_before_the_in_place_relu():
     """hooks.py:5-6 copies a conv's FP output (to the host) the moment it is produced; half of the convs of the net feed
     an in-place ReLU (factoryQ.py:76-77), which must not reach the stored target."""
