@@ -507,66 +507,39 @@ __global__ __launch_bounds__(FPSORT_T) void k_fp_sorted(const float* __restrict_
     disc64((double)vf, alpha, lo, hi, d, &r);
     return r >= (double)kidx;
   };
-  // Per boundary the lane keeps, beside the position, the interval [alo, ahi] of alpha over which that position is
-  // CERTAINLY still right - the value at pos at least 1e-9 level units above the rounding boundary, the value below pos
-  // at least 1e-9 under it (fp64 evaluates u to ~1e-13) - so that an iteration whose alpha stays inside touches no memory
-  // at all for that boundary.  A position that cannot be certified (a value within 1e-9 of the boundary, zeros at the
-  // middle boundary of an even level count) gets the empty interval and is re-checked by pred() every iteration.
-  constexpr double MARGIN = 1e-9, INF = __builtin_huge_val();
-  auto certify = [&](int p, int kidx, double& alo, double& ahi) {
-    const double T = lo + ((double)kidx - 0.5) * d;        // boundary in units of v / alpha
-    const double Tp = T + MARGIN * d, Tm = T - MARGIN * d;
-    alo = 0.0;
-    ahi = INF;
-    if (p < n) {                                           // v[p] / alpha >= Tp
-      const double v = (double)sv[p];
-      if (Tp > 0.0) {
-        if (v > 0.0) ahi = fmin(ahi, (v / Tp) * (1.0 - 1e-12)); else alo = INF;
-      } else if (Tp < 0.0) {
-        if (v < 0.0) alo = fmax(alo, (v / Tp) * (1.0 + 1e-12));
-      } else if (!(v >= 0.0)) {
-        alo = INF;
-      }
-    }
-    if (p > 0) {                                           // v[p - 1] / alpha <= Tm
-      const double v = (double)sv[p - 1];
-      if (Tm > 0.0) {
-        if (v > 0.0) alo = fmax(alo, (v / Tm) * (1.0 + 1e-12));
-      } else if (Tm < 0.0) {
-        if (v < 0.0) ahi = fmin(ahi, (v / Tm) * (1.0 - 1e-12)); else alo = INF;
-      } else if (!(v <= 0.0)) {
-        alo = INF;
-      }
-    }
-  };
+  // Per boundary the lane keeps its position and the two values around it, vlo = v[pos - 1] and vhi = v[pos], in
+  // registers.  An iteration first asks, without touching memory, whether each boundary is CERTAINLY still between its
+  // two neighbours: the fp32 evaluation of u puts vhi more than 2e-4 level units above the rounding boundary and vlo
+  // more than 2e-4 below it (the same test pred() accepts without the exact arithmetic).  Only the boundaries that
+  // fail it are searched again - each lane takes one of its failing boundaries per pass, so a pass costs one search
+  // however many lanes take part - with pred() (exact) from the old position.
+  constexpr float F_INF = __builtin_huge_valf();
   int pos[KB];
-  double alo[KB], ahi[KB];
+  float vlo[KB], vhi[KB];
 #pragma unroll
   for (int kk = 0; kk < KB; ++kk) {
     const int kidx = 1 + lane + 64 * kk;
     int lo_i = -1, hi_i = n;                             // pred(lo_i) false, pred(hi_i) true
-    alo[kk] = 0.0;
-    ahi[kk] = INF;
-    if (kidx <= L1) {
+    if (kidx <= L1)
       while (hi_i - lo_i > 1) {
         const int mid = (lo_i + hi_i) >> 1;
         if (pred(mid, kidx)) hi_i = mid; else lo_i = mid;
       }
-      certify(hi_i, kidx, alo[kk], ahi[kk]);
-    }
     pos[kk] = hi_i;
+    vlo[kk] = (kidx <= L1 && hi_i > 0) ? sv[hi_i - 1] : -F_INF;
+    vhi[kk] = (kidx <= L1 && hi_i < n) ? sv[hi_i] : F_INF;
   }
   const double svt = pre[n];
   const double lo_sv = lo * svt, lo2n = lo * lo * (double)n, d2 = d * d, dlo2 = 2.0 * d * lo;
   const double rv_top = (double)L1 * svt;
-  const long long r_top = (long long)L1 * n, r2_top = (long long)L1 * L1 * n;
-  // this lane's share of sum_k P[pos_k], sum_k pos_k, sum_k (2k-1) pos_k: recomputed only when one of its positions moves
-  double sp = 0.0;
-  unsigned sr = 0, sr2 = 0;
+  const double r_top = (double)L1 * (double)n, r2_top = (double)L1 * (double)L1 * (double)n;
+  // this lane's share of sum_k P[pos_k] and of the integer sums sum_k pos_k, sum_k (2k-1) pos_k (the two packed into one
+  // double: 2^22 * sr2 + sr stays below 2^53), recomputed only when one of its positions moves
+  constexpr double PACK = 4194304.0;                     // 2^22 > sum_k pos_k (<= 255 * 4096)
+  double sp = 0.0, spk = 0.0;
   auto lane_sums = [&]() {
     sp = 0.0;
-    sr = 0;
-    sr2 = 0;
+    unsigned sr = 0, sr2 = 0;
 #pragma unroll
     for (int kk = 0; kk < KB; ++kk) {
       const int kidx = 1 + lane + 64 * kk;
@@ -577,21 +550,22 @@ __global__ __launch_bounds__(FPSORT_T) void k_fp_sorted(const float* __restrict_
         sr2 += (unsigned)((2 * kidx - 1) * p);
       }
     }
+    spk = (double)sr2 * PACK + (double)sr;
   };
   lane_sums();
   double last0 = 0.0, last1 = 0.0;
   int it = 0, done = 0;
   while (!done) {
     const double wsp = wave_sum_f64_dpp(sp);
-    // (the integer sums ride the fp64 DPP tree too: exact below 2^53.  A build that summed them with group_sum_u32 and
-    // instantiated one boundary per lane produced wrong totals on gfx950 although every variation of the surrounding
-    // code - this one included - gives the right ones: kept to the shape that is tested over the whole level range)
-    const double tr = (double)r_top - wave_sum_f64_dpp((double)sr);
-    const double tr2 = (double)r2_top - wave_sum_f64_dpp((double)sr2);
+    const double wpk = wave_sum_f64_dpp(spk);              // exact: integers below 2^53
+    const double wr2 = floor(wpk * (1.0 / PACK));
+    const double wr = wpk - wr2 * PACK;
     const double trv = rv_top - wsp;
+    const double tr = r_top - wr, tr2 = r2_top - wr2;
     const double t0 = d * trv + lo_sv;                         // sum b v
     const double t1 = (d2 * tr2 + dlo2 * tr) + lo2n;           // sum b^2
     const double a_new = t0 / t1;
+    const double ra_new = t1 / t0;                             // independent of the division above (pipelines with it)
     ++it;
     if (it >= max_iter)
       done = 2;
@@ -602,47 +576,57 @@ __global__ __launch_bounds__(FPSORT_T) void k_fp_sorted(const float* __restrict_
     last0 = t0;
     last1 = t1;
     if (done) break;
-    // positions under the new alpha: only the boundaries whose certified interval alpha has left
-    bool moved = false;
-    bool c1_ready = false;
+    c1 = (float)(ra_new * rd);
+    // which boundaries are not certainly in place under the new alpha (registers only)
+    unsigned need = 0;
 #pragma unroll
     for (int kk = 0; kk < KB; ++kk) {
-      const int kidx = 1 + lane + 64 * kk;
-      if (kidx <= L1 && !(alpha >= alo[kk] && alpha <= ahi[kk])) {
-        if (!c1_ready) {
-          c1 = (float)((1.0 / alpha) * rd);
-          c1_ready = true;
+      const float thr = (float)(1 + lane + 64 * kk) - 0.5f;
+      const bool ok = (__builtin_fmaf(vhi[kk], c1, c0) - thr > 2e-4f) && (thr - __builtin_fmaf(vlo[kk], c1, c0) > 2e-4f);
+      need |= ok ? 0u : (1u << kk);
+    }
+    bool moved = false;
+    while (need != 0u) {                                   // one failing boundary of this lane per pass
+      const int k = __builtin_ctz(need);
+      need &= need - 1u;
+      const int kidx = 1 + lane + 64 * k;
+      int p = pos[0];
+#pragma unroll
+      for (int kk = 1; kk < KB; ++kk) p = (k == kk) ? pos[kk] : p;
+      int lo_i, hi_i;
+      if (pred(p, kidx)) {                                 // pos <= p: gallop down
+        hi_i = p;
+        lo_i = p - 1;
+        int step = 1;
+        while (lo_i >= 0 && pred(lo_i, kidx)) {
+          hi_i = lo_i;
+          lo_i -= step;
+          step <<= 1;
         }
-        const int p = pos[kk];
-        int lo_i, hi_i;
-        if (pred(p, kidx)) {                               // pos <= p: gallop down
-          hi_i = p;
-          lo_i = p - 1;
-          int step = 1;
-          while (lo_i >= 0 && pred(lo_i, kidx)) {
-            hi_i = lo_i;
-            lo_i -= step;
-            step <<= 1;
-          }
-          if (lo_i < -1) lo_i = -1;
-        } else {                                           // pos > p: gallop up
-          lo_i = p;
-          hi_i = p + 1;
-          int step = 1;
-          while (hi_i < n && !pred(hi_i, kidx)) {
-            lo_i = hi_i;
-            hi_i += step;
-            step <<= 1;
-          }
-          if (hi_i > n) hi_i = n;
+        if (lo_i < -1) lo_i = -1;
+      } else {                                             // pos > p: gallop up
+        lo_i = p;
+        hi_i = p + 1;
+        int step = 1;
+        while (hi_i < n && !pred(hi_i, kidx)) {
+          lo_i = hi_i;
+          hi_i += step;
+          step <<= 1;
         }
-        while (hi_i - lo_i > 1) {
-          const int mid = (lo_i + hi_i) >> 1;
-          if (pred(mid, kidx)) hi_i = mid; else lo_i = mid;
-        }
-        moved = moved || (hi_i != p);
-        pos[kk] = hi_i;
-        certify(hi_i, kidx, alo[kk], ahi[kk]);
+        if (hi_i > n) hi_i = n;
+      }
+      while (hi_i - lo_i > 1) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (pred(mid, kidx)) hi_i = mid; else lo_i = mid;
+      }
+      moved = moved || (hi_i != p);
+      const float nlo = (hi_i > 0) ? sv[hi_i - 1] : -F_INF;
+      const float nhi = (hi_i < n) ? sv[hi_i] : F_INF;
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        pos[kk] = (k == kk) ? hi_i : pos[kk];
+        vlo[kk] = (k == kk) ? nlo : vlo[kk];
+        vhi[kk] = (k == kk) ? nhi : vhi[kk];
       }
     }
     if (moved) lane_sums();
