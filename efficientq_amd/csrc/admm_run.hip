@@ -280,25 +280,44 @@ int effq_admm_run(const effq_admm_run_args* a) {
     ADMM_RC(effq_spd_inverse(a->A0, n, has_b, plan.rho[first], a->eta, a->ainv_pool, a->inv_ws, a->inv_ws_bytes, s_main));
     ps.close();
   }
-  if (n_inv > 1) {
+  // The later inverses (side stream) are ENQUEUED a few iterations into the loop, not here: their ~30 - 650 launches take
+  // the host 0.2 - 2.6 ms, during which the main stream - done with its own inverse on the small layers - had nothing queued
+  // (under a profiler, at 3 x the launch cost, 6 ms per layer).  The side stream still starts from the fork event recorded
+  // above, i.e. as early as before.
+  bool side_enqueued = (n_inv <= 1);
+  auto enqueue_side_inverses = [&]() -> int {
+    side_enqueued = true;
     if (fork_side && !side_early) {
-      ADMM_HIP(new_event(&ev_fork));
-      ADMM_HIP(hipEventRecord(ev_fork, s_main));       // A0 (and everything before the call) is ready
-      ADMM_HIP(hipStreamWaitEvent(s_side, ev_fork, 0));
+      hipError_t e1 = new_event(&ev_fork);
+      if (e1 == hipSuccess) e1 = hipEventRecord(ev_fork, s_main);       // A0 (and everything before the call) is ready
+      if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s_side, ev_fork, 0);
+      if (e1 != hipSuccess) {
+        effq::set_error("admm_run: side-stream fork -> %s", hipGetErrorString(e1));
+        return EFFQ_ERR_HIP;
+      }
     }
     for (int r = first + 1; r < plan.count; ++r) {
       float* dst = a->ainv_pool + (size_t)(r - first) * ainv_elems;
       void* ws = fork_side ? a->inv_ws_side : a->inv_ws;
       const size_t wsb = fork_side ? a->inv_ws_side_bytes : a->inv_ws_bytes;
       ProfScope ps(g_prof_every > 0, PROF_INVERSE, -1 - r, a, s_side);
-      ADMM_RC(effq_spd_inverse(a->A0, n, has_b, plan.rho[r], a->eta, dst, ws, wsb, s_side));
+      const int rc = effq_spd_inverse(a->A0, n, has_b, plan.rho[r], a->eta, dst, ws, wsb, s_side);
+      if (rc != EFFQ_OK) return rc;
       ps.close();
       if (fork_side) {
-        ADMM_HIP(new_event(&ev_inv[r]));
-        ADMM_HIP(hipEventRecord(ev_inv[r], s_side));
+        hipError_t e2 = new_event(&ev_inv[r]);
+        if (e2 == hipSuccess) e2 = hipEventRecord(ev_inv[r], s_side);
+        if (e2 != hipSuccess) {
+          effq::set_error("admm_run: side-stream event -> %s", hipGetErrorString(e2));
+          return EFFQ_ERR_HIP;
+        }
       }
     }
-  }
+    return EFFQ_OK;
+  };
+  // without a side stream the later inverses run on the main stream: they must be queued before the iterations that use them
+  if (!fork_side && !side_enqueued) ADMM_RC(enqueue_side_inverses());
+  constexpr int SIDE_AFTER_ITERS = 8;
   if (fork_loss)
     for (int e = 0; e < EV_POOL; ++e) ADMM_HIP(new_event(&ev_main[e]));
 
@@ -312,6 +331,8 @@ int effq_admm_run(const effq_admm_run_args* a) {
   const float* Ainv = nullptr;
   for (int i = 0; i < a->iters; ++i) {
     const bool use_shift = plan.shifted_first && i == 0;
+    if (!side_enqueued && (i == SIDE_AFTER_ITERS || (first + 1 < plan.count && i + 1 >= plan.first_iter[first + 1])))
+      ADMM_RC(enqueue_side_inverses());
     if (!use_shift && (cur < 0 || plan.rho[cur] != rho)) {
       int r = first;
       while (r < plan.count && plan.rho[r] != rho) ++r;
@@ -392,6 +413,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
     p_loss.close();
     if (i % a->rho_period == 0) rho = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
   }
+  if (!side_enqueued) ADMM_RC(enqueue_side_inverses());      // (fewer iterations than SIDE_AFTER_ITERS)
   // join: everything the caller reads next (hist, rings) is ordered on the main stream
   if (fork_loss) {
     ADMM_HIP(new_event(&ev_join_loss));
