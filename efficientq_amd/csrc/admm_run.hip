@@ -329,6 +329,13 @@ int effq_admm_run(const effq_admm_run_args* a) {
   float* bm = effq_prox_bm(a->prox_ws, c2, n, &bm_ld);
   bool bm_ready = false;
   const float* Ainv = nullptr;
+  // group size: the last group is evaluated after the chain has finished (it delays the join by one group of losses), so
+  // the cheap losses from the Gram system travel in larger groups than the conv passes.  EFFQ_LOSS_GROUP[_CONV]: A/B switches
+  static const int group_gram = getenv("EFFQ_LOSS_GROUP") ? atoi(getenv("EFFQ_LOSS_GROUP")) : 8;
+  static const int group_conv = getenv("EFFQ_LOSS_GROUP_CONV") ? atoi(getenv("EFFQ_LOSS_GROUP_CONV")) : 4;
+  const int group_env = (a->loss_kind == 4) ? group_gram : group_conv;
+  const int loss_group = (fork_loss && group_env > 1) ? group_env : 1;
+  int loss_next = 0;
   for (int i = 0; i < a->iters; ++i) {
     const bool use_shift = plan.shifted_first && i == 0;
     if (!side_enqueued && (i == SIDE_AFTER_ITERS || (first + 1 < plan.count && i + 1 >= plan.first_iter[first + 1])))
@@ -390,27 +397,40 @@ int effq_admm_run(const effq_admm_run_args* a) {
       }
     }
     p_pr.close();
-    // ---- the loss of this iterate (loss stream) ----
-    if (fork_loss) {
-      hipEvent_t e = ev_main[i % EV_POOL];
+    // ---- the losses (loss stream), in groups of LOSS_GROUP iterates ----
+    // An event record is a barrier packet in the main queue: the next chain kernel starts ~7 us later than it would
+    // behind a kernel (kernel trace: the only gap of an iteration sat between the projection and the next prox GEMM).
+    // The iterates are kept in rings, so the loss stream may as well pick them up a few at a time.
+    if (fork_loss && ((i + 1) % loss_group == 0 || i + 1 == a->iters)) {
+      hipEvent_t e = ev_main[(i / loss_group) % EV_POOL];
       ADMM_HIP(hipEventRecord(e, s_main));
       ADMM_HIP(hipStreamWaitEvent(s_loss, e, 0));
     }
-    double* sq = a->hist + 2 * (size_t)i;
-    ProfScope p_loss(prof, PROF_LOSS, i, a, s_loss);
-    if (a->loss_kind == 1)
-      ADMM_RC(conv3d_calib_step_i8(a->xidx, Gq, bstar, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, st,
-                                   a->w_levels, sq, a->conv_ws, a->conv_ws_bytes, s_loss));
-    else if (a->loss_kind == 2)
-      ADMM_RC(conv3d_calib_step_i8s(a->xidx, Gq, bstar, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, st,
-                                    a->w_levels, i == 0 ? 1 : 0, sq, a->conv_ws, a->conv_ws_bytes, s_loss));
-    else if (a->loss_kind == 4)
-      ADMM_RC(effq_gram_loss(a->loss_Au, a->loss_Bu, a->loss_syy, G, bstar, c2, n, has_b, sq, a->conv_ws, a->conv_ws_bytes,
-                             s_loss));
-    else
-      ADMM_RC(conv3d_quant_calib_step(a->xq, G, bstar, a->y_fp, nullptr, &a->geom, nullptr, 0, sq, nullptr, a->conv_ws,
-                                      a->conv_ws_bytes, s_loss));   // unweighted MSE (quirk Q5)
-    p_loss.close();
+    if (!fork_loss || (i + 1) % loss_group == 0 || i + 1 == a->iters) {
+      for (int j = loss_next; j <= i; ++j) {
+        const float* Gj = a->G_ring + (size_t)j * nw;
+        const int8_t* Gqj = a->Gq_ring ? a->Gq_ring + (size_t)j * nw : nullptr;
+        const float* bj = has_b ? a->b_ring + (size_t)j * c2 : nullptr;
+        const effq_fp_state* stj = a->state_ring + j;
+        double* sq = a->hist + 2 * (size_t)j;
+        const bool profj = g_prof_every > 0 && !(plan.shifted_first && j == 0) && (j % g_prof_every) == g_prof_every / 2;
+        ProfScope p_loss(profj, PROF_LOSS, j, a, s_loss);
+        if (a->loss_kind == 1)
+          ADMM_RC(conv3d_calib_step_i8(a->xidx, Gqj, bj, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, stj,
+                                       a->w_levels, sq, a->conv_ws, a->conv_ws_bytes, s_loss));
+        else if (a->loss_kind == 2)
+          ADMM_RC(conv3d_calib_step_i8s(a->xidx, Gqj, bj, a->y_fp, &a->geom, a->act_alpha_dev, a->act_levels, stj,
+                                        a->w_levels, j == 0 ? 1 : 0, sq, a->conv_ws, a->conv_ws_bytes, s_loss));
+        else if (a->loss_kind == 4)
+          ADMM_RC(effq_gram_loss(a->loss_Au, a->loss_Bu, a->loss_syy, Gj, bj, c2, n, has_b, sq, a->conv_ws,
+                                 a->conv_ws_bytes, s_loss));
+        else
+          ADMM_RC(conv3d_quant_calib_step(a->xq, Gj, bj, a->y_fp, nullptr, &a->geom, nullptr, 0, sq, nullptr, a->conv_ws,
+                                          a->conv_ws_bytes, s_loss));   // unweighted MSE (quirk Q5)
+        p_loss.close();
+      }
+      loss_next = i + 1;
+    }
     if (i % a->rho_period == 0) rho = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
   }
   if (!side_enqueued) ADMM_RC(enqueue_side_inverses());      // (fewer iterations than SIDE_AFTER_ITERS)
