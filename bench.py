@@ -110,7 +110,7 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6    # MI355X dense bf16 matrix peak (MI355X_MICROA
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 NET_TFLOP_PER_VOLUME = 24.55      # conv 21.59 + Gram 2.96 TFLOP per 4x128^3 volume (fp32 algorithmic work)
 # one iteration in SAMPLE is bracketed by HIP events (an event record is a barrier packet in the queue: ~7 us each)
-SAMPLE = int(os.environ.get("EFFQ_BENCH_SAMPLE", "4"))
+SAMPLE = int(os.environ.get("EFFQ_BENCH_SAMPLE", "16"))
 
 
 def log(*a):
