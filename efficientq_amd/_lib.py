@@ -100,6 +100,11 @@ SIGNATURES = {
     "effq_fp_bucket_max": (_SZ, []),
     "effq_fp_bucket_ws_bytes": (_SZ, [_SZ]),
     "effq_fixed_point_bucket": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _SZ, _P]),
+    "effq_fp_bracket_ws_bytes": (_SZ, [_SZ]),
+    "effq_fp_bracket_init": (_I, [_P, _P, _SZ, _I, _I, _P, _SZ, _P]),
+    "effq_fp_bracket_run": (_I, [_P, _SZ, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
+    "effq_fp_bracket_stats": (_I, [_P, _SZ, _I, _D, _D, _P, _P, _P]),
+    "effq_fp_bracket_update": (_I, [_SZ, _I, _D, _D, _D, _I, _P, _P, _P]),
     "effq_fp_check": (_I, [_P, _P, _P]),
     "effq_gram_packed_elems": (_SZ, [_I, _I]),
     "effq_gram_pack": (_I, [_P, _P, _I, _I, _P, _P]),

@@ -15,7 +15,9 @@ from . import _lib
 from ._lib import Geom, check
 
 ADMM_TOL = 1e-5   # layer_helper.py:55
+# tensors from this size on are fitted by the bracketed fixed point (effq_fp_bracket_*)
 import os as _os
+FP_BRACKET_MIN = int(_os.environ.get("EFFQ_FP_BRACKET_MIN", 1 << 18))
 COOP_FIXED_POINT = _os.environ.get("EFFQ_COOP_FP", "1") != "0"
 BUCKET_FIXED_POINT = _os.environ.get("EFFQ_BUCKET_FP", "1") != "0"
 
@@ -206,8 +208,10 @@ class HipOps:
         s0 = self.abs_sum(x)
         if reducer is not None:
             reducer(s0)
-        check(self.lib.effq_fp_init(_ptr(st), _ptr(s0), self.stream), "effq_fp_init")
         batch = max(4, int(guess_iters))
+        if n >= FP_BRACKET_MIN and levels <= 256:
+            return self._fit_scale_bracket(x, n, levels, lo, hi, reducer, batch, st, s0, cap)
+        check(self.lib.effq_fp_init(_ptr(st), _ptr(s0), self.stream), "effq_fp_init")
         while True:
             if reducer is None:
                 check(self.lib.effq_alpha_fixed_point(_ptr(x), n, levels, lo, hi, ADMM_TOL, cap, batch, _ptr(st),
@@ -227,6 +231,41 @@ class HipOps:
             if done == 2:
                 raise RuntimeWarning(f"Exceed maximum iteration ({cap}) for alpha optimization")
             batch = min(max(8, iters // 2), 256)
+
+    def _fit_scale_bracket(self, x, n, levels, lo, hi, reducer, batch, st, s0, cap):
+        """fit_scale on a large tensor by the bracketed fixed point (effq_fp_bracket_*): after the first iterations only
+        the values whose level can still change are read.  Same iterates as the per-iteration passes."""
+        ws = self._workspace("fp_bracket", self.lib.effq_fp_bracket_ws_bytes(n))
+        # unsigned quantiser = post-ReLU input: the first pass already drops the exact zeros
+        check(self.lib.effq_fp_bracket_init(_ptr(st), _ptr(s0), n, levels, int(lo == 0.0), _ptr(ws), ws.numel(),
+                                            self.stream), "effq_fp_bracket_init")
+        while True:
+            if reducer is None:
+                check(self.lib.effq_fp_bracket_run(_ptr(x), n, levels, lo, hi, ADMM_TOL, cap, batch, _ptr(st), _ptr(ws),
+                                                   self.stream), "effq_fp_bracket_run")
+            else:
+                sums = st[2:4]
+                for _ in range(batch):
+                    check(self.lib.effq_fp_bracket_stats(_ptr(x), n, levels, lo, hi, _ptr(st), _ptr(ws), self.stream),
+                          "effq_fp_bracket_stats")
+                    reducer(sums)
+                    check(self.lib.effq_fp_bracket_update(n, levels, lo, hi, ADMM_TOL, cap, _ptr(st), _ptr(ws),
+                                                          self.stream), "effq_fp_bracket_update")
+            alpha, iters, done = self.read_fp_state(st)   # one host sync per batch
+            if done == 1:
+                return alpha, iters, st
+            if done == 2:
+                raise RuntimeWarning(f"Exceed maximum iteration ({cap}) for alpha optimization")
+            batch = min(max(8, iters // 2), 256)
+
+    def fp_bracket_diagnostics(self):
+        """The header of the bracketed fixed point's workspace after a fit (tests, tuning)."""
+        ws = self._ws["fp_bracket"]
+        f = ws[:256].view(torch.float64).cpu()
+        i = ws[:256].view(torch.int64).cpu()
+        return {"blo": float(f[0]), "bhi": float(f[1]), "src": int(i[7]), "G": int(i[10]), "per": int(i[11]),
+                "escapes": int(i[12]), "narrowings": int(i[13]), "visited": int(i[14]), "list_total": int(i[15]),
+                "density": float(f[17]), "widen": int(i[20]), "base": int(i[21]), "z_total": int(i[22])}
 
     def weight_fixed_point(self, wstar, dual, v, levels: int, state, guess: int = 16):
         """Projection input v = wstar + dual and its scale fixed point (EfficientQConv.py:108).

@@ -142,6 +142,34 @@ size_t effq_fp_bucket_ws_bytes(size_t n);
 int effq_fixed_point_bucket(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                             double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
                             void* stream);
+
+/* project_by_iter (layer_helper.py:40-70) on tensors far too large for the chip - the activations of a layer
+ * (PTQConv.py:74-78, EfficientQConv.py:64-72) - without a pass over the whole tensor per iteration.  The level of a value
+ * is monotone in the scale, so a value whose level is the same at both ends of a bracket that confines the remaining
+ * iterates is settled: a narrowing pass moves its contribution into integer tallies and leaves the unsettled values in
+ * a compact list, which is all the following iterations read (and narrow further).  The bracket is a prediction from
+ * the last iterates (up to the limit of the sequence, or a horizon of a few iterations while it converges slowly); an
+ * iterate that leaves it restarts from the tensor or the list of its non-zeros (correctness never depends on it).
+ * Levels are exactly the reference's in every iteration; sums are integers in units of 2^-e (order-independent:
+ * deterministic, identical for any split of the tensor); alpha agrees with the fp64 kernels to ~1e-13, same iteration
+ * count.  levels <= 256.
+ *   init  : state.alpha = abs_sums[0] / abs_sums[1] (the all-reduced sum|x| and count: abs-mean start), unit and plan;
+ *           list_first != 0: the first pass already lists the values that are not settled for every scale (the
+ *           non-zeros - worth it for post-ReLU tensors, a wasted copy for dense ones).
+ *   run   : n_iters x {iteration pass + finish (sums, scalar update, plan of the next pass)}; no-ops once state.done.
+ *   stats : one iteration pass, state.sums = this rank's [sum b*x, sum b*b]   } with data-parallel ranks the caller
+ *   update: scalar update from state.sums + plan of the next pass              } all-reduces state.sums in between
+ * ws: effq_fp_bracket_ws_bytes(n) bytes (three lists of n floats + tallies), owned by the fit between init and its end.
+ * The first 128 bytes of ws are sixteen 8-byte words of diagnostics (bracket, plan, escapes, narrowings, values read). */
+size_t effq_fp_bracket_ws_bytes(size_t n);
+int effq_fp_bracket_init(effq_fp_state* state_dev, const double* abs_sums_dev, size_t n, int levels, int list_first,
+                         void* ws, size_t ws_bytes, void* stream);
+int effq_fp_bracket_run(const float* x, size_t n, int levels, double lo, double hi, double tol, int max_iter, int n_iters,
+                        effq_fp_state* state_dev, void* ws, void* stream);
+int effq_fp_bracket_stats(const float* x, size_t n, int levels, double lo, double hi, effq_fp_state* state_dev, void* ws,
+                          void* stream);
+int effq_fp_bracket_update(size_t n, int levels, double lo, double hi, double tol, int max_iter,
+                           effq_fp_state* state_dev, void* ws, void* stream);
 /* Sticky device-side check used by stream-resident loops: *err_flag_dev = 2 (cap hit; the reference
  * raises, layer_helper.py:62-64) or 3 (not finished) unless state.done == 1. */
 int effq_fp_check(const effq_fp_state* state_dev, int32_t* err_flag_dev, void* stream);
