@@ -63,6 +63,7 @@ class AdmmRunArgs(C.Structure):
                 ("prox_ws", C.c_void_p), ("prox_ws_bytes", C.c_size_t),
                 ("red_ws", C.c_void_p),
                 ("fp_ws", C.c_void_p), ("fp_ws_bytes", C.c_size_t),
+                ("fp_pred", C.c_void_p), ("fp_traj_ws", C.c_void_p), ("fp_traj_ws_bytes", C.c_size_t),
                 ("inv_ws", C.c_void_p), ("inv_ws_bytes", C.c_size_t),
                 ("inv_ws_side", C.c_void_p), ("inv_ws_side_bytes", C.c_size_t),
                 ("conv_ws", C.c_void_p), ("conv_ws_bytes", C.c_size_t),
@@ -105,6 +106,12 @@ SIGNATURES = {
     "effq_fp_bracket_run": (_I, [_P, _SZ, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
     "effq_fp_bracket_stats": (_I, [_P, _SZ, _I, _D, _D, _P, _P, _P]),
     "effq_fp_bracket_update": (_I, [_SZ, _I, _D, _D, _D, _I, _P, _P, _P]),
+    "effq_fp_traj_max": (_SZ, []),
+    "effq_fp_traj_ws_bytes": (_SZ, [_SZ]),
+    "effq_fp_traj_pred_bytes": (_SZ, []),
+    "effq_fixed_point_traj": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _P, _SZ, _P]),
+    "effq_fixed_point_bucket_rec": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _SZ, _P, _P]),
+    "effq_fixed_point_coop_rec": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _P, _P]),
     "effq_fp_check": (_I, [_P, _P, _P]),
     "effq_gram_packed_elems": (_SZ, [_I, _I]),
     "effq_gram_pack": (_I, [_P, _P, _I, _I, _P, _P]),

@@ -208,6 +208,28 @@ int effq_admm_run(const effq_admm_run_args* a) {
     set_error("admm_run: fixed-point workspace %zu < %zu", a->fp_ws_bytes, effq_fp_bucket_ws_bytes(nw));
     return EFFQ_ERR_WORKSPACE;
   }
+  // ... and, where it is the faster one, the projection that starts from the previous iteration's iterates
+  // (effq_fixed_point_traj: one launch, no grid barrier).  Its last workgroup scans lists whose length follows the drift
+  // of the iterates from call to call, which is largest right after rho has changed: measured inside the calibration
+  // (ms per calibration, all on one box: older kernels only 715; trajectory kernel from the third iteration of a layer on
+  // 743; from 5 / 10 / 15 iterations after a change of rho, layers of 65 536 ... 2^20 weights only: 702 / 703 / 699; and
+  // for larger layers from 30 iterations after: 698).  The iterations in between run the kernels above, which leave
+  // their iterates behind.  EFFQ_FP_TRAJ=0, EFFQ_FP_TRAJ_AFTER[_BIG], EFFQ_FP_TRAJ_MIN, EFFQ_FP_TRAJ_LEVELS: A/B switches
+  static const bool traj_on = !(getenv("EFFQ_FP_TRAJ") && atoi(getenv("EFFQ_FP_TRAJ")) == 0);
+  static const bool traj_rho_old = !(getenv("EFFQ_FP_TRAJ_RHO") && atoi(getenv("EFFQ_FP_TRAJ_RHO")) == 0);
+  // (at 16 levels the fixed point takes ~50 iterations: the one hull slot for everything past the seventh keeps a third
+  // of the values on the list, and the older kernels are faster - measured, scripts/prof_fp_traj.py)
+  static const int traj_levels = getenv("EFFQ_FP_TRAJ_LEVELS") ? atoi(getenv("EFFQ_FP_TRAJ_LEVELS")) : 4;
+  static const int traj_after_env = getenv("EFFQ_FP_TRAJ_AFTER") ? atoi(getenv("EFFQ_FP_TRAJ_AFTER")) : 12;
+  static const int traj_after_big = getenv("EFFQ_FP_TRAJ_AFTER_BIG") ? atoi(getenv("EFFQ_FP_TRAJ_AFTER_BIG")) : 30;
+  static const size_t traj_min = getenv("EFFQ_FP_TRAJ_MIN") ? (size_t)atoll(getenv("EFFQ_FP_TRAJ_MIN")) : 65536;
+  const int traj_after = (nw > ((size_t)1 << 20)) ? traj_after_big : traj_after_env;
+  const bool traj = traj_on && a->fp_pred != nullptr && a->fp_traj_ws != nullptr && a->w_levels <= traj_levels && nw >= traj_min &&
+                    nw <= effq_fp_traj_max();
+  if (traj && a->fp_traj_ws_bytes < effq_fp_traj_ws_bytes(nw)) {
+    set_error("admm_run: trajectory fixed-point workspace %zu < %zu", a->fp_traj_ws_bytes, effq_fp_traj_ws_bytes(nw));
+    return EFFQ_ERR_WORKSPACE;
+  }
   const RhoPlan plan = plan_rhos(a->rho, a->rho_max, a->iters, a->rho_period);
   EFFQ_CHECK_ARG(!plan.overflow);
   const int first = plan.shifted_first ? 1 : 0;
@@ -264,6 +286,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
   hipEvent_t ev_fork = nullptr, ev_join_loss = nullptr, ev_join_side = nullptr;
 
   ADMM_HIP(hipMemsetAsync(a->dual, 0, nw * sizeof(float), s_main));                 // dual <- 0 (EfficientQConv.py:40)
+  if (traj) ADMM_HIP(hipMemsetAsync(a->fp_pred, 0, effq_fp_traj_pred_bytes(), s_main));   // nothing known about this layer
   // the inverse the first iterations need, on the main stream; the later ones on the side stream, which starts at once,
   // beside the first inverse (all of them only read A0): with n = 13825 an inverse takes longer than the 50 iterations it has
   // to be ready after, and the chain waited for each of the three later ones in turn (LiTS: 3.08 -> 3.03 s per calibration;
@@ -336,6 +359,8 @@ int effq_admm_run(const effq_admm_run_args* a) {
   const int group_env = (a->loss_kind == 4) ? group_gram : group_conv;
   const int loss_group = (fork_loss && group_env > 1) ? group_env : 1;
   int loss_next = 0;
+  bool rho_changed_last = false;
+  int rho_changed_at = 0;          // first iteration that ran with the current rho
   for (int i = 0; i < a->iters; ++i) {
     const bool use_shift = plan.shifted_first && i == 0;
     if (!side_enqueued && (i == SIDE_AFTER_ITERS || (first + 1 < plan.count && i + 1 >= plan.first_iter[first + 1])))
@@ -370,15 +395,24 @@ int effq_admm_run(const effq_admm_run_args* a) {
                               a->prox_ws, a->prox_ws_bytes, s_main));
     p_prox.close();
     ProfScope p_fp(prof, PROF_FIXED_POINT, i, a, s_main);
-    if (bucket)
-      ADMM_RC(effq_fixed_point_bucket(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
-                                      a->fp_ws, a->fp_ws_bytes, s_main));
+    // (rho changes at the end of iterations 0, period, 2 period ...: the iteration after sees a rescaled dual)
+    const bool after_rho = i > 0 && (i - 1) % a->rho_period == 0 && rho_changed_last;
+    void* rec = traj ? a->fp_pred : nullptr;
+    // (iterations since rho last changed: the drift from call to call - and with it the length of the lists the
+    // trajectory kernel's single last workgroup has to scan - is largest right after a change)
+    const int since_rho = i - rho_changed_at;
+    if (traj && i > 1 && !(traj_rho_old && after_rho) && since_rho >= traj_after)
+      ADMM_RC(effq_fixed_point_traj(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
+                                    a->fp_pred, a->fp_traj_ws, a->fp_traj_ws_bytes, s_main));
+    else if (bucket)
+      ADMM_RC(effq_fixed_point_bucket_rec(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels,
+                                          st, a->fp_ws, a->fp_ws_bytes, rec, s_main));
     else if (nw <= effq_fp_small_max())
       ADMM_RC(effq_fixed_point_small(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
                                      s_main));
     else
-      ADMM_RC(effq_fixed_point_coop(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
-                                    a->red_ws, s_main));
+      ADMM_RC(effq_fixed_point_coop_rec(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels,
+                                        st, a->red_ws, rec, s_main));
     p_fp.close();
     ProfScope p_pr(prof, PROF_PROJECT, i, a, s_main);
     {
@@ -431,7 +465,12 @@ int effq_admm_run(const effq_admm_run_args* a) {
       }
       loss_next = i + 1;
     }
-    if (i % a->rho_period == 0) rho = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
+    if (i % a->rho_period == 0) {
+      const double rho_new = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
+      rho_changed_last = rho_new != rho;
+      if (rho_changed_last) rho_changed_at = i + 1;
+      rho = rho_new;
+    }
   }
   if (!side_enqueued) ADMM_RC(enqueue_side_inverses());      // (fewer iterations than SIDE_AFTER_ITERS)
   // join: everything the caller reads next (hist, rings) is ordered on the main stream

@@ -21,6 +21,7 @@
 // Two paths: n <= 32768 - ONE workgroup, values and tables in LDS (k_fps); larger - four launches with global
 // atomics (k_fpg_sum / k_fpg_count / k_fpg_scan / k_fpg_scatter_iter), the last workgroup to finish regrouping iterates.
 #include "common.h"
+#include "fp_level.h"
 
 namespace effq {
 
@@ -114,7 +115,7 @@ struct TabSeg {
 template <typename Tab>
 __device__ __forceinline__ void fpb_iterate(const float* __restrict__ vals, const Tab& tab, const FpbGeo& g, size_t n,
                                             double tot_abs, double lo, double hi, double d, int levels, double tol,
-                                            int max_iter, FpbShared& sh, effq_fp_state* st) {
+                                            int max_iter, FpbShared& sh, effq_fp_state* st, FptPred* pred = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nthr = levels - 1;                 // level boundaries k = 1 .. L-1
   int p2 = 1;
@@ -147,6 +148,7 @@ __device__ __forceinline__ void fpb_iterate(const float* __restrict__ vals, cons
       break;
     }
     const int par = it & 1;
+    if (tid == 0) fpt_note(pred, it, alpha);     // (the iterates seed the next call's predictions: fixed_point_traj.hip)
     if (active) {
       const double tk = alpha * kpos;
       const double guard = fmax(fabs(tk) * 9.5367431640625e-07, alpha * 9.313225746154785e-10);   // 2^-20, 2^-30
@@ -273,6 +275,10 @@ __device__ __forceinline__ void fpb_iterate(const float* __restrict__ vals, cons
     st->sums[1] = last1;
     st->iters = it;
     st->done = done;
+    if (pred != nullptr) {
+      for (int j = 0; j < FPT_SLOTS; ++j) fpt_finish_slot(pred, j, it, alpha);
+      fpt_finish_head(pred, it, tot_abs, levels);
+    }
   }
 }
 
@@ -284,7 +290,7 @@ constexpr int FPS2_MAXN = 32768;
 template <int PER>   // register slots per thread (values stay in registers through the three build passes)
 __global__ __launch_bounds__(FPS2_T) void k_fps(const float* __restrict__ a, const float* __restrict__ b2,
                                                 float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
-                                                double hi, double d, int levels, double tol, int max_iter) {
+                                                double hi, double d, int levels, double tol, int max_iter, FptPred* pred) {
   __builtin_amdgcn_s_setprio(3);        // latency-bound, shares its CU with loss-conv waves
 
   constexpr int B = FPS2_B;
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(FPS2_T) void k_fps(const float* __restrict__ a, con
   FPB_TRACE(5);
   if (tid >= FPB_TI) return;                    // the barriers below only count the surviving waves
   TabFlat tab{off, spre};
-  fpb_iterate(vals, tab, g, n, tot, lo, hi, d, levels, tol, max_iter, sh, st);
+  fpb_iterate(vals, tab, g, n, tot, lo, hi, d, levels, tol, max_iter, sh, st, pred);
 }
 
 // ---- path G: large tensors, four launches ------------------------------------------------------------------------------------
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(FPG_SEG) void k_fpg_scan(int B, FpgWs w) {
 
 __global__ __launch_bounds__(FPG_T) void k_fpg_scatter_iter(const float* __restrict__ src, size_t n, int B, FpgWs w,
                                                             effq_fp_state* st, double lo, double hi, double d, int levels,
-                                                            double tol, int max_iter) {
+                                                            double tol, int max_iter, FptPred* pred) {
   __builtin_amdgcn_s_setprio(3);
 
   __shared__ FpbShared sh;
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(FPG_T) void k_fpg_scatter_iter(const float* __restr
   __syncthreads();
   const double tot = w.hdr->tot_abs;
   TabSeg tab{w.off, w.spre, w.segc, w.segs, B};
-  fpb_iterate(w.grouped, tab, g, n, tot, lo, hi, d, levels, tol, max_iter, sh, st);
+  fpb_iterate(w.grouped, tab, g, n, tot, lo, hi, d, levels, tol, max_iter, sh, st, pred);
 }
 
 static size_t fps_lds_bytes(size_t n) {
@@ -799,9 +805,10 @@ size_t effq_fp_bucket_max(void) { return (size_t)1 << 23; }
 
 size_t effq_fp_bucket_ws_bytes(size_t n) { return n <= (size_t)FPS2_MAXN ? 256 : fpg_ws_bytes(n); }
 
-int effq_fixed_point_bucket(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
-                            double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
-                            void* stream) {
+int effq_fixed_point_bucket_rec(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                                double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
+                                void* pred_dev, void* stream) {
+  FptPred* pred = reinterpret_cast<FptPred*>(pred_dev);
   EFFQ_CHECK_ARG(a && state_dev && n > 0 && levels >= 2 && levels <= 256 && hi > lo && max_iter > 0);
   EFFQ_CHECK_ARG(n <= effq_fp_bucket_max());
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
@@ -832,7 +839,7 @@ int effq_fixed_point_bucket(const float* a, const float* b, float* v_out, size_t
     }
     hipLaunchKernelGGL(k_fpg_scan, dim3((unsigned)(B / FPG_SEG)), dim3(FPG_SEG), 0, st, B, w);
     hipLaunchKernelGGL(k_fpg_scatter_iter, dim3((unsigned)blocks), dim3(FPG_T), 0, st, src, n, B, w, state_dev, lo, hi, d,
-                       levels, tol, max_iter);
+                       levels, tol, max_iter, pred);
     EFFQ_LAUNCH_CHECK();
     return EFFQ_OK;
   }
@@ -847,13 +854,20 @@ int effq_fixed_point_bucket(const float* a, const float* b, float* v_out, size_t
   const size_t lds = fps_lds_bytes(n);
   const int per = (int)((n + FPS2_T - 1) / FPS2_T);
   if (per <= 8)
-    hipLaunchKernelGGL(k_fps<8>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter);
+    hipLaunchKernelGGL(k_fps<8>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter, pred);
   else if (per <= 16)
-    hipLaunchKernelGGL(k_fps<16>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter);
+    hipLaunchKernelGGL(k_fps<16>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter, pred);
   else
-    hipLaunchKernelGGL(k_fps<32>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter);
+    hipLaunchKernelGGL(k_fps<32>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter, pred);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
+}
+
+int effq_fixed_point_bucket(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                            double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
+                            void* stream) {
+  return effq_fixed_point_bucket_rec(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, ws, ws_bytes, nullptr,
+                                     stream);
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include "common.h"
+#include "fp_level.h"
 
 namespace effq {
 
@@ -689,7 +690,8 @@ template <int T>
 __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, const float* __restrict__ b2,
                                                    float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
                                                    double hi, double d, double tol, int max_iter, double* partials,
-                                                   unsigned int* counter, unsigned spin_limit) {
+                                                   unsigned int* counter, unsigned spin_limit, FptPred* pred,
+                                                   int levels) {
   __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
   // a workspace poisoned by an earlier time-out: report and leave, touching nothing (uniform across the grid: the
   // poison word only ever goes 0 -> 1 before this launch started, or during it - then the barrier below catches it)
@@ -789,6 +791,7 @@ __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, cons
   const double lo_sv = lo * sv, lo2n = lo * lo * (double)n, d2 = d * d, dlo2 = 2.0 * d * lo;
   while (!done) {
     const int par = (it + 1) & 1;          // parity 0 was used by the abs-sum epoch
+    if (wg == 0 && tid == 0) fpt_note(pred, it, alpha);      // (seeds the next call's predictions: fixed_point_traj.hip)
     const float c1 = (float)((1.0 / alpha) * rd);
     double arv = 0.0;
     long long sr = 0, sr2 = 0;
@@ -840,6 +843,10 @@ __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, cons
     st->sums[1] = last1;
     st->iters = it;
     st->done = done;
+    if (pred != nullptr) {
+      for (int j = 0; j < FPT_SLOTS; ++j) fpt_finish_slot(pred, j, it, alpha);
+      fpt_finish_head(pred, it, tot, levels);
+    }
   }
   // leave the barrier counter at zero for the next launch: every workgroup is past its last poll when it gets
   // here, so the last one to check out (counter[1]) resets both words - no memset command per call.  (After a
@@ -1235,6 +1242,13 @@ int effq_fp_coop_set_spin_limit(unsigned int polls) {
 
 int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                           double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* stream) {
+  return effq_fixed_point_coop_rec(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, ws, nullptr, stream);
+}
+
+int effq_fixed_point_coop_rec(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                              double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* pred_dev,
+                              void* stream) {
+  FptPred* pred = reinterpret_cast<FptPred*>(pred_dev);
   EFFQ_CHECK_ARG(a && state_dev && ws && n > 0 && levels >= 2 && hi > lo && max_iter > 0);
   EFFQ_CHECK_ARG(n <= effq_fp_coop_max());
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
@@ -1290,7 +1304,7 @@ int effq_fixed_point_coop(const float* a, const float* b, float* v_out, size_t n
     return EFFQ_OK;
   }
   hipLaunchKernelGGL(k_fp_coop<FPC_T>, dim3(G), dim3(FPC_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, tol,
-                     max_iter, partials, counter, g_fpc_spin_limit);
+                     max_iter, partials, counter, g_fpc_spin_limit, pred, levels);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

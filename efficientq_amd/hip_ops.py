@@ -20,6 +20,7 @@ import os as _os
 FP_BRACKET_MIN = int(_os.environ.get("EFFQ_FP_BRACKET_MIN", 1 << 18))
 COOP_FIXED_POINT = _os.environ.get("EFFQ_COOP_FP", "1") != "0"
 BUCKET_FIXED_POINT = _os.environ.get("EFFQ_BUCKET_FP", "1") != "0"
+TRAJ_FIXED_POINT = _os.environ.get("EFFQ_FP_TRAJ", "1") != "0"
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -299,6 +300,45 @@ class HipOps:
                                                _ptr(state), _ptr(ws), ws.numel(), self.stream),
               "effq_fixed_point_bucket")
 
+    def new_fp_pred(self) -> torch.Tensor:
+        """Zero-filled prediction state of effq_fixed_point_traj (nothing known)."""
+        return torch.zeros(self.lib.effq_fp_traj_pred_bytes(), dtype=torch.uint8, device=self.device)
+
+    def fixed_point_traj(self, a, b, v, levels: int, state, pred, lo: float = -1.0, hi: float = 1.0):
+        """project_by_iter of v = a + b from the previous call's iterates (`pred`), one launch (effq_fixed_point_traj)."""
+        n = a.numel()
+        ws = self._workspace("fp_traj", self.lib.effq_fp_traj_ws_bytes(n))
+        check(self.lib.effq_fixed_point_traj(_ptr(a), _ptr(b), _ptr(v), n, levels, lo, hi, ADMM_TOL, 100 * levels,
+                                             _ptr(state), _ptr(pred), _ptr(ws), ws.numel(), self.stream),
+              "effq_fixed_point_traj")
+
+    def fixed_point_bucket_rec(self, a, b, v, levels: int, state, pred, lo: float = -1.0, hi: float = 1.0):
+        n = a.numel()
+        ws = self._workspace("fp_bucket", self.lib.effq_fp_bucket_ws_bytes(n))
+        check(self.lib.effq_fixed_point_bucket_rec(_ptr(a), _ptr(b), _ptr(v), n, levels, lo, hi, ADMM_TOL, 100 * levels,
+                                                   _ptr(state), _ptr(ws), ws.numel(), _ptr(pred), self.stream),
+              "effq_fixed_point_bucket_rec")
+
+    def fixed_point_coop_rec(self, a, b, v, levels: int, state, pred, lo: float = -1.0, hi: float = 1.0):
+        check(self.lib.effq_fixed_point_coop_rec(_ptr(a), _ptr(b), _ptr(v), a.numel(), levels, lo, hi, ADMM_TOL,
+                                                 100 * levels, _ptr(state), _ptr(self._red_ws), _ptr(pred), self.stream),
+              "effq_fixed_point_coop_rec")
+
+    @staticmethod
+    def read_fp_pred(pred: torch.Tensor):
+        """FptPred of csrc/fp_level.h as a dict (tests, diagnostics)."""
+        i32 = pred[:16].view(torch.int32).cpu()
+        f = pred[16:16 + 8 * 40].view(torch.float64).cpu()
+        i64 = pred[16 + 8 * 40:16 + 8 * 45].view(torch.int64).cpu()
+        fn = pred[16 + 8 * 45:16 + 8 * 53].view(torch.float64).cpu()
+        j64 = pred[16 + 8 * 53:16 + 8 * 63].view(torch.int64).cpu()
+        K = int(i32[0])
+        return {"K": K, "e": int(i32[1]), "lo": f[0:8].tolist(), "hi": f[8:16].tolist(), "eps": f[16:24].tolist(),
+                "eps_n": fn.tolist(), "calls": int(i64[0]), "warm_iters": int(i64[1]), "full_iters": int(i64[2]),
+                "listed": int(i64[3]), "list_max": int(i64[4]), "ring_iters": int(j64[0]), "ring_listed": int(j64[1]),
+                "trace_us": [(int(j64[2 + k]) - int(j64[2])) / 100.0 for k in range(5)],
+                "mean_us_phase1_setup_loop": [int(j64[7 + k]) / 100.0 / max(int(i64[0]), 1) for k in range(3)]}
+
     def fp_check(self, state, err_flag):
         check(self.lib.effq_fp_check(_ptr(state), _ptr(err_flag), self.stream), "effq_fp_check")
 
@@ -553,6 +593,10 @@ class HipOps:
         inv_side = self._workspace("inv_side", self.lib.effq_spd_inverse_ws_bytes(n)) if n_inv > 1 else None
         fpw = (self._workspace("fp_bucket", self.lib.effq_fp_bucket_ws_bytes(nw))
                if nw <= self.lib.effq_fp_bucket_max() and BUCKET_FIXED_POINT else None)
+        # weight projection from the previous iteration's iterates (effq_fixed_point_traj)
+        traj = TRAJ_FIXED_POINT and levels <= 16 and 16384 <= nw <= self.lib.effq_fp_traj_max()   # (the library decides)
+        tws = self._workspace("fp_traj", self.lib.effq_fp_traj_ws_bytes(nw)) if traj else None
+        r.fp_pred = torch.zeros(self.lib.effq_fp_traj_pred_bytes(), dtype=torch.uint8, device=dev) if traj else None
         if loss_kind == 4:
             cws = self._workspace("gram_loss", self.lib.effq_gram_loss_ws_bytes(n))
         elif loss_kind == 1:
@@ -587,6 +631,7 @@ class HipOps:
         a.prox_ws, a.prox_ws_bytes = p(prox), prox.numel()
         a.red_ws = p(self._red_ws)
         a.fp_ws, a.fp_ws_bytes = p(fpw), (fpw.numel() if fpw is not None else 0)
+        a.fp_pred, a.fp_traj_ws, a.fp_traj_ws_bytes = p(r.fp_pred), p(tws), (tws.numel() if tws is not None else 0)
         a.inv_ws, a.inv_ws_bytes = p(inv), inv.numel()
         a.inv_ws_side, a.inv_ws_side_bytes = p(inv_side), (inv_side.numel() if inv_side is not None else 0)
         a.conv_ws, a.conv_ws_bytes = p(cws), cws.numel()

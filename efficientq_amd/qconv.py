@@ -390,6 +390,8 @@ class EfficientQConvHIP(PTQConv):
         best_G, best_b, best = ops.admm_select_best(run)
         info = ops.admm_read(run, best)                                    # one host sync per layer
         t_loop = _time.perf_counter() - t_loop0
+        if _os.environ.get("EFFQ_FP_TRAJ_STATS") and getattr(run, "fp_pred", None) is not None:     # diagnostic
+            print(f"[fp_traj] {getattr(self, 'name', '?')} nw={nw}: {ops.read_fp_pred(run.fp_pred)}", flush=True)
         a_w, w_iters, hist, best_h = info["alpha_w"], info["w_iters"], info["hist"], info["best"]
         if info["err"] != 0:                                               # layer_helper.py:62-64
             if info["err"] == 2:

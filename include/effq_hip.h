@@ -143,6 +143,30 @@ int effq_fixed_point_bucket(const float* a, const float* b, float* v_out, size_t
                             double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
                             void* stream);
 
+/* project_by_iter for the weight projection INSIDE the ADMM loop (EfficientQConv.py:108 -> layer_helper.py:40-70) in ONE
+ * launch, from the previous ADMM iteration's iterates: v_k = w*_k + dual_{k-1} differs little from v_{k-1}, so the i-th
+ * iterate of this call lies within 1e-3 ... 1e-9 of the i-th iterate of the last one.  `pred_dev`
+ * (effq_fp_traj_pred_bytes() bytes of device memory, zero-filled = nothing known) carries them from call to call with a
+ * margin each.  One pass over the values by all workgroups forms v, sums |v| and tallies - in integers - every value
+ * whose level is the same at both ends of a predicted bracket (the level is monotone in the scale); the few per cent
+ * that are not go to a list.  The last workgroup to finish then iterates: an iterate inside its predicted bracket costs
+ * one scan of the list; one outside costs a pass of that single workgroup over v (slow, rare).  Levels are exactly the
+ * reference's, alpha within ~1e-15 of the fp64 kernels', same iteration count, deterministic.  levels <= 16,
+ * n <= effq_fp_traj_max().  ws: effq_fp_traj_ws_bytes(n), zero-filled once (its counters are left at zero).
+ * The *_rec variants of the older fixed points do the same work as their namesakes and, when pred_dev != NULL, leave
+ * their iterates in it (the first call of a layer, calls after rho has changed). */
+size_t effq_fp_traj_max(void);
+size_t effq_fp_traj_ws_bytes(size_t n);
+size_t effq_fp_traj_pred_bytes(void);
+int effq_fixed_point_traj(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                          double tol, int max_iter, effq_fp_state* state_dev, void* pred_dev, void* ws, size_t ws_bytes,
+                          void* stream);
+int effq_fixed_point_bucket_rec(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                                double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
+                                void* pred_dev, void* stream);
+int effq_fixed_point_coop_rec(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                              double tol, int max_iter, effq_fp_state* state_dev, void* ws, void* pred_dev, void* stream);
+
 /* project_by_iter (layer_helper.py:40-70) on tensors far too large for the chip - the activations of a layer
  * (PTQConv.py:74-78, EfficientQConv.py:64-72) - without a pass over the whole tensor per iteration.  The level of a value
  * is monotone in the scale, so a value whose level is the same at both ends of a bracket that confines the remaining
@@ -360,6 +384,10 @@ typedef struct effq_admm_run_args {
   void* prox_ws; size_t prox_ws_bytes;
   void* red_ws;
   void* fp_ws; size_t fp_ws_bytes;
+  /* effq_fixed_point_traj for the weight projection (levels <= 16, 16384 <= weights <= effq_fp_traj_max()): fp_pred =
+   * effq_fp_traj_pred_bytes() of device memory (the run zero-fills it), fp_traj_ws = effq_fp_traj_ws_bytes(weights),
+   * zero-filled once.  NULL: the older fixed points only. */
+  void* fp_pred; void* fp_traj_ws; size_t fp_traj_ws_bytes;
   void* inv_ws; size_t inv_ws_bytes;
   void* inv_ws_side; size_t inv_ws_side_bytes;
   void* conv_ws; size_t conv_ws_bytes;
