@@ -68,6 +68,7 @@ class AdmmRunArgs(C.Structure):
                 ("inv_ws_side", C.c_void_p), ("inv_ws_side_bytes", C.c_size_t),
                 ("conv_ws", C.c_void_p), ("conv_ws_bytes", C.c_size_t),
                 ("stream_main", C.c_void_p), ("stream_loss", C.c_void_p), ("stream_side", C.c_void_p),
+                ("stream_side2", C.c_void_p), ("inv_ws_side2", C.c_void_p), ("inv_ws_side2_bytes", C.c_size_t),
                 ("loss_Au", C.c_void_p), ("loss_Bu", C.c_void_p), ("loss_syy", C.c_void_p)]
 
 

@@ -241,6 +241,11 @@ int effq_admm_run(const effq_admm_run_args* a) {
   hipStream_t s_loss = a->stream_loss ? as_stream(a->stream_loss) : s_main;
   hipStream_t s_side = (a->stream_side && a->inv_ws_side) ? as_stream(a->stream_side) : s_main;
   const bool fork_loss = s_loss != s_main, fork_side = s_side != s_main;
+  // a second side stream: the later inverses alternate between the two (a Gauss-Jordan sweep is a chain of ~100 dependent
+  // launches with serial pivot phases: two sweeps side by side fill each other's bubbles, and the last inverse of a wide
+  // layer is ready before the chain reaches the iteration that needs it)
+  hipStream_t s_side2 = (fork_side && a->stream_side2 && a->inv_ws_side2) ? as_stream(a->stream_side2) : s_side;
+  const bool two_sides = s_side2 != s_side;
 
   // events: one per inverse formed on the side stream, a small pool for main -> loss, one each for the joins.  They
   // come from a per-thread, per-device pool that is never destroyed (a wait captures the record that precedes it, so
@@ -297,6 +302,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
     ADMM_HIP(new_event(&ev_fork));
     ADMM_HIP(hipEventRecord(ev_fork, s_main));         // A0 (and everything before the call) is ready
     ADMM_HIP(hipStreamWaitEvent(s_side, ev_fork, 0));
+    if (two_sides) ADMM_HIP(hipStreamWaitEvent(s_side2, ev_fork, 0));
   }
   {
     ProfScope ps(g_prof_every > 0, PROF_INVERSE, -1, a, s_main);
@@ -314,6 +320,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
       hipError_t e1 = new_event(&ev_fork);
       if (e1 == hipSuccess) e1 = hipEventRecord(ev_fork, s_main);       // A0 (and everything before the call) is ready
       if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s_side, ev_fork, 0);
+      if (e1 == hipSuccess && two_sides) e1 = hipStreamWaitEvent(s_side2, ev_fork, 0);
       if (e1 != hipSuccess) {
         effq::set_error("admm_run: side-stream fork -> %s", hipGetErrorString(e1));
         return EFFQ_ERR_HIP;
@@ -321,15 +328,17 @@ int effq_admm_run(const effq_admm_run_args* a) {
     }
     for (int r = first + 1; r < plan.count; ++r) {
       float* dst = a->ainv_pool + (size_t)(r - first) * ainv_elems;
-      void* ws = fork_side ? a->inv_ws_side : a->inv_ws;
-      const size_t wsb = fork_side ? a->inv_ws_side_bytes : a->inv_ws_bytes;
-      ProfScope ps(g_prof_every > 0, PROF_INVERSE, -1 - r, a, s_side);
-      const int rc = effq_spd_inverse(a->A0, n, has_b, plan.rho[r], a->eta, dst, ws, wsb, s_side);
+      const bool on2 = two_sides && ((r - first) % 2 == 0);       // first later inverse on side 1, the next on side 2 ...
+      hipStream_t sr = on2 ? s_side2 : s_side;
+      void* ws = !fork_side ? a->inv_ws : (on2 ? a->inv_ws_side2 : a->inv_ws_side);
+      const size_t wsb = !fork_side ? a->inv_ws_bytes : (on2 ? a->inv_ws_side2_bytes : a->inv_ws_side_bytes);
+      ProfScope ps(g_prof_every > 0, PROF_INVERSE, -1 - r, a, sr);
+      const int rc = effq_spd_inverse(a->A0, n, has_b, plan.rho[r], a->eta, dst, ws, wsb, sr);
       if (rc != EFFQ_OK) return rc;
       ps.close();
       if (fork_side) {
         hipError_t e2 = new_event(&ev_inv[r]);
-        if (e2 == hipSuccess) e2 = hipEventRecord(ev_inv[r], s_side);
+        if (e2 == hipSuccess) e2 = hipEventRecord(ev_inv[r], sr);
         if (e2 != hipSuccess) {
           effq::set_error("admm_run: side-stream event -> %s", hipGetErrorString(e2));
           return EFFQ_ERR_HIP;
@@ -483,6 +492,12 @@ int effq_admm_run(const effq_admm_run_args* a) {
     ADMM_HIP(new_event(&ev_join_side));
     ADMM_HIP(hipEventRecord(ev_join_side, s_side));
     ADMM_HIP(hipStreamWaitEvent(s_main, ev_join_side, 0));
+    if (two_sides) {
+      hipEvent_t ev_join_side2 = nullptr;
+      ADMM_HIP(new_event(&ev_join_side2));
+      ADMM_HIP(hipEventRecord(ev_join_side2, s_side2));
+      ADMM_HIP(hipStreamWaitEvent(s_main, ev_join_side2, 0));
+    }
   }
   destroy_events();
 #undef ADMM_HIP

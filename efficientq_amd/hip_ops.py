@@ -21,6 +21,7 @@ FP_BRACKET_MIN = int(_os.environ.get("EFFQ_FP_BRACKET_MIN", 1 << 18))
 COOP_FIXED_POINT = _os.environ.get("EFFQ_COOP_FP", "1") != "0"
 BUCKET_FIXED_POINT = _os.environ.get("EFFQ_BUCKET_FP", "1") != "0"
 TRAJ_FIXED_POINT = _os.environ.get("EFFQ_FP_TRAJ", "1") != "0"
+SIDE2_STREAM = _os.environ.get("EFFQ_SIDE2", "1") != "0"
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -110,6 +111,12 @@ class HipOps:
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(self.device)
         return self._side
+
+    def side_stream2(self):
+        """A third stream: the later inverses of a layer alternate between the two side streams."""
+        if getattr(self, "_side2", None) is None:
+            self._side2 = torch.cuda.Stream(self.device)
+        return self._side2
 
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
         """Library workspace `key`, zero-filled when (re)allocated.  The fill is issued on the stream the NEXT op
@@ -591,6 +598,8 @@ class HipOps:
         prox = self._workspace("prox", self.lib.effq_prox_ws_bytes(c2, n))
         inv = self._workspace("inv", self.lib.effq_spd_inverse_ws_bytes(n))
         inv_side = self._workspace("inv_side", self.lib.effq_spd_inverse_ws_bytes(n)) if n_inv > 1 else None
+        inv_side2 = (self._workspace("inv_side2", self.lib.effq_spd_inverse_ws_bytes(n))
+                     if n_inv > 2 and SIDE2_STREAM else None)
         fpw = (self._workspace("fp_bucket", self.lib.effq_fp_bucket_ws_bytes(nw))
                if nw <= self.lib.effq_fp_bucket_max() and BUCKET_FIXED_POINT else None)
         # weight projection from the previous iteration's iterates (effq_fixed_point_traj)
@@ -638,6 +647,9 @@ class HipOps:
         a.stream_main = main.cuda_stream
         a.stream_loss = loss_s.cuda_stream if loss_s is not None else None
         a.stream_side = side_s.cuda_stream if inv_side is not None else None
+        if inv_side2 is not None:
+            a.stream_side2 = self.side_stream2().cuda_stream
+            a.inv_ws_side2, a.inv_ws_side2_bytes = p(inv_side2), inv_side2.numel()
         r.keep = (A0, B0, W0, b0, y, xq, xidx, al, loss_gram)       # the call only enqueues: keep every operand alive
         check(self.lib.effq_admm_run(C.byref(a)), "effq_admm_run")
         return r

@@ -392,6 +392,9 @@ typedef struct effq_admm_run_args {
   void* inv_ws_side; size_t inv_ws_side_bytes;
   void* conv_ws; size_t conv_ws_bytes;
   void* stream_main; void* stream_loss; void* stream_side;
+  /* optional second side stream with its own inverse workspace: the later inverses alternate between the two side
+   * streams (their serial pivot phases overlap); NULL: one side stream */
+  void* stream_side2; void* inv_ws_side2; size_t inv_ws_side2_bytes;
   /* loss_kind 4: the loss of an iterate from the layer's unweighted Gram system (effq_gram_loss): Au [n][n], Bu [c2][n]
    * (effq_gram_accum_i8_unw), syy = one device double, sum y^2 over this rank's voxels; conv_ws = effq_gram_loss_ws_bytes(n)
    * zero-filled once.  NULL for the other kinds. */
