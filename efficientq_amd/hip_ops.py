@@ -665,14 +665,18 @@ class HipOps:
         return best_G, best_b, best
 
     @staticmethod
-    def admm_read(run, best):
-        """ONE device->host copy per layer: loss history, best, the last scale, fixed-point iteration counts, error."""
-        pack = torch.cat([run.hist[:, 0], best, run.state_ring[-1, :1], run.state_ring[:, 4],
-                          run.err.to(torch.float64)]).cpu()
+    def admm_read(run, best, extra=None):
+        """ONE device->host copy per layer: loss history, best, the last scale, fixed-point iteration counts, error
+        (and `extra`, a small fp64 device tensor the caller wants read in the same copy)."""
+        parts = [run.hist[:, 0], best, run.state_ring[-1, :1], run.state_ring[:, 4], run.err.to(torch.float64)]
+        if extra is not None:
+            parts.append(extra.to(torch.float64).reshape(-1))
+        pack = torch.cat(parts).cpu()
         it = run.iters
         w_iters = pack[it + 3: 2 * it + 3].contiguous().view(torch.int32)[0::2].tolist()
         return dict(hist=pack[:it].tolist(), best=pack[it:it + 2].tolist(), alpha_w=float(pack[it + 2]),
-                    w_iters=w_iters, err=int(pack[-1]))
+                    w_iters=w_iters, err=int(pack[2 * it + 3]),
+                    extra=pack[2 * it + 4:].tolist() if extra is not None else None)
 
     def shift_terms(self, rho: float, eta: float, rho_inv: float) -> int:
         d = rho_inv - rho

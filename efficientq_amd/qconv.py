@@ -278,7 +278,7 @@ class EfficientQConvHIP(PTQConv):
     @staticmethod
     def _std(m: torch.Tensor) -> float:
         """Unbiased std from [sum, sumsq, n] (Tensor.std(), EfficientQConv.py:46,48)."""
-        s, ss, n = m.tolist()
+        s, ss, n = m.tolist() if hasattr(m, "tolist") else m
         return math.sqrt(max(ss - s * s / n, 0.0) / (n - 1))
 
     def ptq(self, x):
@@ -294,25 +294,27 @@ class EfficientQConvHIP(PTQConv):
         c2 = self.out_channels
         nw = W0.numel() // c2
 
-        # rho_scale = max(numel(y)*std(y) / (numel(W)*std(W)), 1)          (EfficientQConv.py:43-49)
+        # rho_scale = max(numel(y)*std(y) / (numel(W)*std(W)), 1) [* mean(att)]     (EfficientQConv.py:43-49, :51-62)
+        # the three moment triples are enqueued first and read by ONE device->host copy (each read empties the queue:
+        # the device idles for the round trip)
         my = ops.moments(yn)
         syy_local = my[1:2].clone()           # sum y^2 over THIS rank's voxels (the loss from the Gram system adds it)
         my = red(my)
         mw = ops.moments(W0)
-        y_dim = my[2].item()
-        rho_scale = max(y_dim * self._std(my) / (W0.numel() * self._std(mw)), 1.0)
-
         att = None
         if self.lwq_verbose:
             print(f'Calibrating {self.name}')
-        if self.mask_pyramid:                                              # (:51-62)
+        if self.mask_pyramid:
             for mask in self.mask_pyramid:
                 if tuple(mask.shape[1:]) == tuple(self.output_fp.shape[2:]):
                     att = mask.to(dev).contiguous()
                     break
-        if att is not None:
-            ma = red(ops.moments(att))
-            rho_scale *= ma[0].item() / ma[2].item()
+        ma = red(ops.moments(att)) if att is not None else None
+        mh = torch.cat([my, mw] + ([ma] if ma is not None else [])).tolist()
+        y_dim = mh[2]
+        rho_scale = max(y_dim * self._std(mh[0:3]) / (W0.numel() * self._std(mh[3:6])), 1.0)
+        if ma is not None:
+            rho_scale *= mh[6] / mh[8]
 
         act_iters = 0
         xidx = None
@@ -388,10 +390,20 @@ class EfficientQConvHIP(PTQConv):
         t_enq = _time.perf_counter() - t_loop0     # host time to enqueue the 200 iterations (diagnostic)
         red(run.hist)
         best_G, best_b, best = ops.admm_select_best(run)
-        info = ops.admm_read(run, best)                                    # one host sync per layer
+        # (:161-166) the final loss - and, from the same pass, the layer's quantised output, which forward() hands to the
+        # next layer right after this call (PTQConv.py:160-163 runs the same conv a second time): the fp32 activation
+        # quant-dequant is fused into the tile load, exactly as in the quantised forward.  Enqueued BEFORE the layer's
+        # one device->host read, which then carries its two sums as well.
+        fuse = self.q_act and not self._act_inited
+        out, fin = ops.conv_step(xn if fuse else xq, best_G, best_b, geom, yn, att,
+                                 act_alpha=self.alpha_act.data if fuse else None,
+                                 act_levels=self.qlvl_act if fuse else 0, want_out=True)
+        self._ptq_out = out if (fuse or not self.q_act) else None
+        red(fin)
+        info = ops.admm_read(run, best, extra=fin)                         # ONE host sync for the loop and the final loss
         t_loop = _time.perf_counter() - t_loop0
         if _os.environ.get("EFFQ_FP_TRAJ_STATS") and getattr(run, "fp_pred", None) is not None:     # diagnostic
-            print(f"[fp_traj] {getattr(self, 'name', '?')} nw={nw}: {ops.read_fp_pred(run.fp_pred)}", flush=True)
+            print(f"[fp_traj] {getattr(self, 'name', '?')}: {ops.read_fp_pred(run.fp_pred)}", flush=True)
         a_w, w_iters, hist, best_h = info["alpha_w"], info["w_iters"], info["hist"], info["best"]
         if info["err"] != 0:                                               # layer_helper.py:62-64
             if info["err"] == 2:
@@ -408,17 +420,7 @@ class EfficientQConvHIP(PTQConv):
         if has_b:
             self.bias.data = best_b
         self.alpha_w.data = torch.tensor(a_w, dtype=x.dtype, device=dev)   # LAST iterate's scale (quirk Q6)
-
-        # (:161-166) the final loss - and, from the same pass, the layer's quantised output, which forward() hands to the
-        # next layer right after this call (PTQConv.py:160-163 runs the same conv a second time): the fp32 activation
-        # quant-dequant is fused into the tile load, exactly as in the quantised forward
-        fuse = self.q_act and not self._act_inited
-        out, fin = ops.conv_step(xn if fuse else xq, best_G, best_b, geom, yn, att,
-                                 act_alpha=self.alpha_act.data if fuse else None,
-                                 act_levels=self.qlvl_act if fuse else 0, want_out=True)
-        self._ptq_out = out if (fuse or not self.q_act) else None
-        red(fin)
-        fin_h = fin.tolist()
+        fin_h = info["extra"]
         numel = y_dim * 1.0
         lossf = (fin_h[1] if att is not None else fin_h[0]) / numel
         if self.layer_loss is not None:

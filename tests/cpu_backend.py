@@ -172,8 +172,9 @@ class OracleOps:
         return run.G_ring[bi].clone(), (run.b_ring[bi].clone() if run.has_b else None), best
 
     @staticmethod
-    def admm_read(run, best):
-        return dict(hist=run.hist[:, 0].tolist(), best=best.tolist(), alpha_w=run.alpha_w, w_iters=run.w_iters, err=0)
+    def admm_read(run, best, extra=None):
+        return dict(hist=run.hist[:, 0].tolist(), best=best.tolist(), alpha_w=run.alpha_w, w_iters=run.w_iters, err=0,
+                    extra=extra.double().reshape(-1).tolist() if extra is not None else None)
 
     def conv_step(self, x_ndhwc, weight, bias, geom, y_ndhwc=None, att=None, act_alpha=None, act_levels=0,
                   want_out=False, sqerr=None):
