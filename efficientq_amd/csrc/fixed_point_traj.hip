@@ -93,6 +93,16 @@ __global__ __launch_bounds__(FPT_T) void k_fpt(const float* __restrict__ a, cons
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wg = blockIdx.x;
   constexpr int NW = FPT_T / 64;
   const long long tr0 = wall_clock64();
+  // the operands first: their loads are in flight while the predictions are fetched and the bracket ends set up
+  float va[FPT_EPT], vb[FPT_EPT];
+  const size_t base = (size_t)wg * FPT_WGV + tid;
+#pragma unroll
+  for (int e = 0; e < FPT_EPT; ++e) {
+    const size_t i = base + (size_t)e * FPT_T;
+    const size_t ic = (i < n) ? i : (n - 1);
+    va[e] = a[ic];
+    vb[e] = (b2 != nullptr) ? b2[ic] : 0.0f;
+  }
   const int K = pred->K;
   const bool warm = K > 0 && pred->e_valid != 0;
   const int e_units = pred->e;
@@ -122,13 +132,8 @@ __global__ __launch_bounds__(FPT_T) void k_fpt(const float* __restrict__ a, cons
 
   // ---- phase 1 ------------------------------------------------------------------------------------------------------
   float vv[FPT_EPT];
-  const size_t base = (size_t)wg * FPT_WGV + tid;
 #pragma unroll
-  for (int e = 0; e < FPT_EPT; ++e) {            // loads first: all in flight together
-    const size_t i = base + (size_t)e * FPT_T;
-    const size_t ic = (i < n) ? i : (n - 1);
-    vv[e] = (b2 != nullptr) ? (a[ic] + b2[ic]) : a[ic];
-  }
+  for (int e = 0; e < FPT_EPT; ++e) vv[e] = (b2 != nullptr) ? (va[e] + vb[e]) : va[e];
   double sabs = 0.0, sv = 0.0;
   long long tw_ru[FPT_SLOTS], tw_ct[FPT_SLOTS], tr_ru[FPT_SLOTS], tr_ct[FPT_SLOTS];
 #pragma unroll
