@@ -236,7 +236,7 @@ class OpTimer:
                 # It runs on the bf16 matrix cores with both fp32 operands split in three (six exact bf16 products per
                 # fp32 product, fp32 accumulate): the flops it EXECUTES are 6 x 2 c2 n^2, and that is
                 # what is set against the dense bf16 peak
-                tile = "256,256,4,2" if c2 > 128 else "128,256,2,4"
+                tile = "256,256,4,2" if c2 > 128 else "128,128,2,4"
                 return ("mfma", 6.0 * 2.0 * c2 * n * n, PEAK_BF16_MFMA_TFLOPS, "TFLOP/s",
                         f"k_prox_gemm_b3<{tile}> (+ ~5 us k_prox_reduce4) (c2={c2}, n={n}: the fp32 product 2 c2 n^2 = "
                         f"{2.0 * c2 * n * n / 1e9:.2f} GFLOP evaluated as 6 bf16 MFMA products of operands split in "

@@ -747,6 +747,10 @@ static ProxPlan prox_plan(int c2, int n) {
     // 256 (128) x 256 tiles on the bf16 matrix cores (k_prox_gemm_b3), one workgroup of 8 waves per CU: K split so that
     // the grid is about one round of the 256 CUs, at least 16 K tiles per slice
     p.variant = (p.c2p >= 256) ? 5 : 6; p.gx = (n + 255) / 256; p.gy = (p.c2p >= 256) ? p.c2p / 256 : 1;
+    // 128 rows: 128 x 128 tiles (28 column tiles x 9 K slices at n = 3457: half the partial slabs of the 128 x 256 tiling,
+    // two workgroups per CU): 37.7 against 43.1 us alone, 35.8 against 44.3 in situ.  EFFQ_PROX_B3_128=0: A/B switch
+    static const int b3_128 = getenv("EFFQ_PROX_B3_128") ? atoi(getenv("EFFQ_PROX_B3_128")) : 1;
+    if (p.variant == 6 && b3_128) { p.variant = 7; p.gx = (n + 127) / 128; }
     const int tiles5 = p.gx * p.gy, nkt5 = p.ldb / B3_K;
     int s5 = (256 + tiles5 / 2) / tiles5;
     if (s5 > nkt5 / 16) s5 = nkt5 / 16;
@@ -890,9 +894,10 @@ static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, 
 #define EFFQ_PROX_LAUNCH(MT, WM, WN, NTN)                                                                              \
   hipLaunchKernelGGL((k_prox_gemm<MT, WM, WN, NTN>), grid, dim3(256), 0, st, Bm, ldb, Ainv, lda, n, c2, has_bias ? 1 : 0, \
                      wstar, bstar, part, ldb)
-    if (pl.variant == 5 || pl.variant == 6) {
+    if (pl.variant == 5 || pl.variant == 6 || pl.variant == 7) {
       const size_t lds5 = (size_t)2 * 3 * (256 + 256) * B3_LD * sizeof(__bf16);      // two stages
       const size_t lds6 = (size_t)2 * 3 * (128 + 256) * B3_LD * sizeof(__bf16);
+      const size_t lds7 = (size_t)2 * 3 * (128 + 128) * B3_LD * sizeof(__bf16);
       static bool attr5[64] = {};
       int dev5 = 0;
       EFFQ_HIP(hipGetDevice(&dev5));
@@ -902,13 +907,18 @@ static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
         EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prox_gemm_b3<128, 256, 2, 4>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6));
+        EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prox_gemm_b3<128, 128, 2, 4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7));
         attr5[dev5] = true;
       }
       if (pl.variant == 5)
         hipLaunchKernelGGL((k_prox_gemm_b3<256, 256, 4, 2>), grid, dim3(512), lds5, st, Bm, ldb, Ainv, lda, n, c2,
                            has_bias ? 1 : 0, wstar, bstar, part, ldb);
-      else
+      else if (pl.variant == 6)
         hipLaunchKernelGGL((k_prox_gemm_b3<128, 256, 2, 4>), grid, dim3(512), lds6, st, Bm, ldb, Ainv, lda, n, c2,
+                           has_bias ? 1 : 0, wstar, bstar, part, ldb);
+      else
+        hipLaunchKernelGGL((k_prox_gemm_b3<128, 128, 2, 4>), grid, dim3(512), lds7, st, Bm, ldb, Ainv, lda, n, c2,
                            has_bias ? 1 : 0, wstar, bstar, part, ldb);
     } else
     switch (pl.variant) {
