@@ -103,7 +103,8 @@ __global__ __launch_bounds__(FPT_T) void k_fpt(const float* __restrict__ a, cons
     va[e] = a[ic];
     vb[e] = (b2 != nullptr) ? b2[ic] : 0.0f;
   }
-  const int K = pred->K;
+  // (a prediction buffer the caller did not zero-fill must not index past the slots)
+  const int K = min(max(pred->K, 0), FPT_SLOTS);
   const bool warm = K > 0 && pred->e_valid != 0;
   const int e_units = pred->e;
   const double inv_q = ldexp(1.0, e_units);

@@ -78,7 +78,7 @@ __device__ __forceinline__ void fpt_finish_slot(FptPred* p, int j, int iters, do
     h = fmax(h, alpha_final);
   }
   double eps = FPT_EPS_NEW, eps_n = FPT_EPS_NEW;
-  if (j < p->K) {
+  if (j < p->K && p->K <= FPT_SLOTS) {
     // the drift from call to call is noisy (ADMM iterates oscillate: factors of 5 - 10 between consecutive calls), so the
     // margin follows its recent MAXIMUM: 4 x the last drift, and never below 0.85 of the previous margin.  Replayed on
     // the oracle's iterates of a 32 -> 32 layer (tests/diagnostics/traj_policy_sim.py): 1.3 % of the iterates fall
