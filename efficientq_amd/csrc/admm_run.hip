@@ -13,8 +13,15 @@
 #include <stdlib.h>
 #include <vector>
 #include "common.h"
+#include "project_dual.h"
 
 extern "C" {
+int effq_fixed_point_small_fused(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                                 double tol, int max_iter, effq_fp_state* state_dev, const effq::ProjFused* pf_in,
+                                 void* stream);   // quant_reduce.hip (internal)
+int effq_fixed_point_bucket_fused(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                                  double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
+                                  void* pred_dev, const effq::ProjFused* pf_in, int* fused_out, void* stream);   // fixed_point_bucket.hip (internal)
 int effq_project_dual_next(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
                            float* dual, float dual_div, int8_t* Gq_out, size_t n, int32_t* err_flag_dev, float* Bm,
                            const float* B0, const float* W0, int nwrow, int nb0, int ldb, double rho_next, double eta,
@@ -404,32 +411,69 @@ int effq_admm_run(const effq_admm_run_args* a) {
                               a->prox_ws, a->prox_ws_bytes, s_main));
     p_prox.close();
     ProfScope p_fp(prof, PROF_FIXED_POINT, i, a, s_main);
+    // The projection + dual update as the EPILOGUE of the fixed point where that is a single workgroup (weights <= 32768):
+    // one launch per iteration less.  The projection also leaves the right-hand side of the NEXT prox solve in the prox
+    // workspace; the first solve of the layer builds Bm itself (bias column, padding).
+    double rho_next = rho;
+    if (i % a->rho_period == 0) rho_next = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
+    const bool next_rhs = fuse_build && i + 1 < a->iters;
+    ProjFused pf;
+    memset(&pf, 0, sizeof(pf));
+    bool fuse_proj = false;
+    {
+      const int nwrow = n - has_b;
+      const uintptr_t al16 = reinterpret_cast<uintptr_t>(a->v) | reinterpret_cast<uintptr_t>(a->wstar) |
+                             reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(a->dual) |
+                             (next_rhs ? (reinterpret_cast<uintptr_t>(a->W0) | reinterpret_cast<uintptr_t>(bm)) : 0);
+      const bool vec_ok = (al16 & 15) == 0 && (reinterpret_cast<uintptr_t>(Gq) & 3) == 0 && (nw % 4) == 0 &&
+                          (!next_rhs || ((nwrow % 4) == 0 && (bm_ld % 4) == 0));
+      // measured (us per iteration, fused against fixed point + projection): 2048 weights 13.8 against 12.2 + 7.1, 3456 at
+      // 256 levels 231.8 against 229.3 + 8.3 - but 27648 weights on the bucketed kernel 56.3 against 33.6 + 7.1: only the
+      // 256 threads of its iteration phase are left for the epilogue.  So: the all-values kernel's layers only
+      // (EFFQ_FUSE_PROJ=2 also fuses the bucketed single-workgroup kernel: A/B switch)
+      static const int fuse_proj_mode = getenv("EFFQ_FUSE_PROJ") ? atoi(getenv("EFFQ_FUSE_PROJ")) : 1;
+      const bool one_wg = (bucket && nw <= 32768 && fuse_proj_mode >= 2) || (!bucket && nw <= effq_fp_small_max());
+      if (vec_ok && one_wg && fuse_proj_mode != 0) {
+        fuse_proj = true;
+        pf.wstar = a->wstar; pf.G = G; pf.dual = a->dual; pf.Gq = Gq; pf.err_flag = a->err_flag;
+        pf.d = 2.0 / (double)(a->w_levels - 1); pf.dual_div = dual_div; pf.lm1 = a->w_levels - 1;
+        pf.n4 = (unsigned)(nw / 4);
+        if (next_rhs) {
+          pf.nx.Bm = bm; pf.nx.B0 = a->B0; pf.nx.W0 = a->W0; pf.nx.nwrow = nwrow; pf.nx.n = n; pf.nx.ldb = bm_ld;
+          pf.nx.rho = (float)rho_next; pf.nx.eta = (float)a->eta;
+        }
+      }
+    }
     // (rho changes at the end of iterations 0, period, 2 period ...: the iteration after sees a rescaled dual)
     const bool after_rho = i > 0 && (i - 1) % a->rho_period == 0 && rho_changed_last;
     void* rec = traj ? a->fp_pred : nullptr;
     // (iterations since rho last changed: the drift from call to call - and with it the length of the lists the
     // trajectory kernel's single last workgroup has to scan - is largest right after a change)
     const int since_rho = i - rho_changed_at;
-    if (traj && i > 1 && !(traj_rho_old && after_rho) && since_rho >= traj_after)
+    if (traj && i > 1 && !(traj_rho_old && after_rho) && since_rho >= traj_after) {
+      fuse_proj = false;
       ADMM_RC(effq_fixed_point_traj(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
                                     a->fp_pred, a->fp_traj_ws, a->fp_traj_ws_bytes, s_main));
-    else if (bucket)
-      ADMM_RC(effq_fixed_point_bucket_rec(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels,
-                                          st, a->fp_ws, a->fp_ws_bytes, rec, s_main));
-    else if (nw <= effq_fp_small_max())
-      ADMM_RC(effq_fixed_point_small(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
-                                     s_main));
-    else
+    } else if (bucket) {
+      int fused = 0;
+      ADMM_RC(effq_fixed_point_bucket_fused(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol,
+                                            100 * a->w_levels, st, a->fp_ws, a->fp_ws_bytes, rec,
+                                            fuse_proj ? &pf : nullptr, &fused, s_main));
+      fuse_proj = fused != 0;
+    } else if (nw <= effq_fp_small_max()) {
+      ADMM_RC(effq_fixed_point_small_fused(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol,
+                                           100 * a->w_levels, st, fuse_proj ? &pf : nullptr, s_main));
+    } else {
+      fuse_proj = false;
       ADMM_RC(effq_fixed_point_coop_rec(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels,
                                         st, a->red_ws, rec, s_main));
+    }
     p_fp.close();
-    ProfScope p_pr(prof, PROF_PROJECT, i, a, s_main);
-    {
-      // the projection also leaves the right-hand side of the NEXT prox solve in the prox workspace (one launch per
-      // iteration less on the critical path); the first solve of the layer builds Bm itself (bias column, padding)
-      double rho_next = rho;
-      if (i % a->rho_period == 0) rho_next = (rho * 2 <= a->rho_max) ? rho * 2 : a->rho_max;
-      if (fuse_build && i + 1 < a->iters) {
+    if (fuse_proj) {
+      bm_ready = next_rhs;
+    } else {
+      ProfScope p_pr(prof, PROF_PROJECT, i, a, s_main);
+      if (next_rhs) {
         ADMM_RC(effq_project_dual_next(a->v, a->wstar, st, a->w_levels, G, a->dual, dual_div, Gq, nw, a->err_flag, bm,
                                        a->B0, a->W0, n - has_b, n, bm_ld, rho_next, a->eta, s_main));
         bm_ready = true;
@@ -438,8 +482,8 @@ int effq_admm_run(const effq_admm_run_args* a) {
                                           s_main));
         bm_ready = false;
       }
+      p_pr.close();
     }
-    p_pr.close();
     // ---- the losses (loss stream), in groups of LOSS_GROUP iterates ----
     // An event record is a barrier packet in the main queue: the next chain kernel starts ~7 us later than it would
     // behind a kernel (kernel trace: the only gap of an iteration sat between the projection and the next prox GEMM).

@@ -22,6 +22,7 @@
 // atomics (k_fpg_sum / k_fpg_count / k_fpg_scan / k_fpg_scatter_iter), the last workgroup to finish regrouping iterates.
 #include "common.h"
 #include "fp_level.h"
+#include "project_dual.h"
 
 namespace effq {
 
@@ -115,7 +116,8 @@ struct TabSeg {
 template <typename Tab>
 __device__ __forceinline__ void fpb_iterate(const float* __restrict__ vals, const Tab& tab, const FpbGeo& g, size_t n,
                                             double tot_abs, double lo, double hi, double d, int levels, double tol,
-                                            int max_iter, FpbShared& sh, effq_fp_state* st, FptPred* pred = nullptr) {
+                                            int max_iter, FpbShared& sh, effq_fp_state* st, FptPred* pred = nullptr,
+                                            double* alpha_out = nullptr, int* done_out = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nthr = levels - 1;                 // level boundaries k = 1 .. L-1
   int p2 = 1;
@@ -280,6 +282,8 @@ __device__ __forceinline__ void fpb_iterate(const float* __restrict__ vals, cons
       fpt_finish_head(pred, it, tot_abs, levels);
     }
   }
+  if (alpha_out != nullptr) *alpha_out = alpha;      // (every thread of the iteration phase holds the same values)
+  if (done_out != nullptr) *done_out = done;
 }
 
 // ---- path S: one workgroup, everything in LDS ---------------------------------------------------------------------------
@@ -288,9 +292,9 @@ constexpr int FPS2_B = 2048;
 constexpr int FPS2_MAXN = 32768;
 
 template <int PER>   // register slots per thread (values stay in registers through the three build passes)
-__global__ __launch_bounds__(FPS2_T) void k_fps(const float* __restrict__ a, const float* __restrict__ b2,
-                                                float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
-                                                double hi, double d, int levels, double tol, int max_iter, FptPred* pred) {
+__global__ __launch_bounds__(FPS2_T) void k_fps(const float* __restrict__ a, const float* b2, float* v_out, size_t n,
+                                                effq_fp_state* st, double lo, double hi, double d, int levels, double tol,
+                                                int max_iter, FptPred* pred, ProjFused pf) {
   __builtin_amdgcn_s_setprio(3);        // latency-bound, shares its CU with loss-conv waves
 
   constexpr int B = FPS2_B;
@@ -471,7 +475,12 @@ __global__ __launch_bounds__(FPS2_T) void k_fps(const float* __restrict__ a, con
   FPB_TRACE(5);
   if (tid >= FPB_TI) return;                    // the barriers below only count the surviving waves
   TabFlat tab{off, spre};
-  fpb_iterate(vals, tab, g, n, tot, lo, hi, d, levels, tol, max_iter, sh, st, pred);
+  double alpha_fin = 0.0;
+  int done_fin = 0;
+  fpb_iterate(vals, tab, g, n, tot, lo, hi, d, levels, tol, max_iter, sh, st, pred, &alpha_fin, &done_fin);
+  // the projection + dual update of this ADMM iteration as the epilogue of the same launch (the FPB_TI surviving threads;
+  // v_out was stored before the build passes' barriers)
+  if (pf.G != nullptr) proj_fused_epilogue(pf, v_out, alpha_fin, done_fin, tid, FPB_TI);
 }
 
 // ---- path G: large tensors, four launches ------------------------------------------------------------------------------------
@@ -805,10 +814,30 @@ size_t effq_fp_bucket_max(void) { return (size_t)1 << 23; }
 
 size_t effq_fp_bucket_ws_bytes(size_t n) { return n <= (size_t)FPS2_MAXN ? 256 : fpg_ws_bytes(n); }
 
+int effq_fixed_point_bucket_fused(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                                  double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
+                                  void* pred_dev, const ProjFused* pf_in, int* fused_out, void* stream);
+
 int effq_fixed_point_bucket_rec(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                                 double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
                                 void* pred_dev, void* stream) {
+  return effq_fixed_point_bucket_fused(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, ws, ws_bytes, pred_dev,
+                                       nullptr, nullptr, stream);
+}
+
+// internal (admm_run.hip): pf_in != NULL and n <= 32768 (one workgroup): the projection of the ADMM iteration runs as the
+// kernel's epilogue and *fused_out = 1; larger tensors ignore pf_in (*fused_out = 0: the caller launches the projection)
+int effq_fixed_point_bucket_fused(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                                  double tol, int max_iter, effq_fp_state* state_dev, void* ws, size_t ws_bytes,
+                                  void* pred_dev, const ProjFused* pf_in, int* fused_out, void* stream) {
   FptPred* pred = reinterpret_cast<FptPred*>(pred_dev);
+  ProjFused pf;
+  memset(&pf, 0, sizeof(pf));
+  if (fused_out != nullptr) *fused_out = 0;
+  if (pf_in != nullptr && n <= (size_t)FPS2_MAXN && v_out != nullptr) {
+    pf = *pf_in;
+    if (fused_out != nullptr) *fused_out = 1;
+  }
   EFFQ_CHECK_ARG(a && state_dev && n > 0 && levels >= 2 && levels <= 256 && hi > lo && max_iter > 0);
   EFFQ_CHECK_ARG(n <= effq_fp_bucket_max());
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
@@ -854,11 +883,11 @@ int effq_fixed_point_bucket_rec(const float* a, const float* b, float* v_out, si
   const size_t lds = fps_lds_bytes(n);
   const int per = (int)((n + FPS2_T - 1) / FPS2_T);
   if (per <= 8)
-    hipLaunchKernelGGL(k_fps<8>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter, pred);
+    hipLaunchKernelGGL(k_fps<8>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter, pred, pf);
   else if (per <= 16)
-    hipLaunchKernelGGL(k_fps<16>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter, pred);
+    hipLaunchKernelGGL(k_fps<16>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter, pred, pf);
   else
-    hipLaunchKernelGGL(k_fps<32>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter, pred);
+    hipLaunchKernelGGL(k_fps<32>, dim3(1), dim3(FPS2_T), lds, st, a, b, v_out, n, state_dev, lo, hi, d, levels, tol, max_iter, pred, pf);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

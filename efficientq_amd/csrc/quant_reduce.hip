@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "fp_level.h"
+#include "project_dual.h"
 
 namespace effq {
 
@@ -35,14 +36,6 @@ __device__ __forceinline__ float qd32(float x, float alpha, float lo, float hi, 
   float r = rintf((t - lo) / d);
   *idx = r;
   return (r * d + lo) * alpha;
-}
-
-__device__ __forceinline__ double disc64(double x, double alpha, double lo, double hi, double d, double* idx) {
-  double t = x / alpha;
-  t = fmin(fmax(t, lo), hi);
-  double r = rint((t - lo) / d);
-  *idx = r;
-  return r * d + lo;
 }
 
 // Same level index as disc64 (bit-exact), without the two IEEE fp64 divisions on the common path: the
@@ -78,21 +71,6 @@ struct LevelStats {
   double arx, sx;          // sum r x, sum x (sx only when lo != 0)
   long long sr, sr2;       // sum r, sum r^2
 };
-struct LevelConsts {
-  float c1, c0, lmax;
-  double alpha, lo, hi, d;
-  bool need_sx;
-};
-__device__ __forceinline__ LevelConsts level_consts(double alpha, double lo, double hi, double d) {
-  LevelConsts c;
-  const double rd = 1.0 / d;
-  c.c1 = (float)((1.0 / alpha) * rd);
-  c.c0 = (float)(-lo * rd);
-  c.lmax = (float)rint((hi - lo) * rd);
-  c.alpha = alpha; c.lo = lo; c.hi = hi; c.d = d;
-  c.need_sx = lo != 0.0;
-  return c;
-}
 __device__ __forceinline__ void level_accum(float xf, const LevelConsts& c, LevelStats& a) {
   float u = __builtin_fmaf(xf, c.c1, c.c0);
   u = fminf(fmaxf(u, 0.0f), c.lmax);
@@ -286,9 +264,9 @@ constexpr int FPS_T = 1024;
 // u = (v/alpha - lo)/d (error <= 3e-5 at 256 levels) and is accepted when u is not within 2e-4 of a rounding boundary;
 // otherwise (2e-4 of the values) the reference's own fp64 arithmetic (disc64) decides: the level indices are exact.
 template <int T, int PER>
-__global__ __launch_bounds__(T) void k_fp_small(const float* __restrict__ a, const float* __restrict__ b2,
-                                                float* __restrict__ v_out, size_t n, effq_fp_state* st, double lo,
-                                                double hi, double d, double tol, int max_iter) {
+__global__ __launch_bounds__(T) void k_fp_small(const float* __restrict__ a, const float* b2, float* v_out, size_t n,
+                                                effq_fp_state* st, double lo, double hi, double d, double tol,
+                                                int max_iter, ProjFused pf) {
   constexpr int NW = T / 64;
   __shared__ double part[2][3][NW];
   // one workgroup on the critical path of the ADMM chain, sharing its CU with the waves of the loss conv of the previous
@@ -394,6 +372,10 @@ __global__ __launch_bounds__(T) void k_fp_small(const float* __restrict__ a, con
     st->sums[1] = last1;
     st->iters = it;
     st->done = done;
+  }
+  if (pf.G != nullptr) {                       // the projection + dual update of this ADMM iteration, same launch
+    __syncthreads();                           // v_out of every thread is in place
+    proj_fused_epilogue(pf, v_out, alpha, done, tid, T);
   }
 }
 
@@ -893,16 +875,6 @@ __global__ __launch_bounds__(TPB) void k_presum(const float* __restrict__ a, con
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) o[i] = a[i] + b[i];
 }
 
-// Optional extra output of the projection: Bm = B0 + eta [W0|b0] + rho (G - dual) for the next iteration's prox solve,
-// element for element what k_build_b4 (solve.hip) computes - one launch per ADMM iteration less.  The bias column and the
-// zero padding of Bm do not depend on the iterate: they stay as the first build of the layer left them.
-struct ProjNext {
-  float* Bm;
-  const float* B0;
-  const float* W0;
-  int nwrow, n, ldb;       // weights per output channel, row length of B0, row length of Bm
-  float rho, eta;
-};
 __global__ __launch_bounds__(TPB) void k_project_dual(const float* __restrict__ v, const float* __restrict__ wstar,
                                                       const effq_fp_state* __restrict__ st, double d,
                                                       float* __restrict__ G, float* __restrict__ dual,
@@ -949,57 +921,8 @@ __global__ __launch_bounds__(TPB) void k_project_dual4(const float* __restrict__
   const float alpha32 = (float)alpha;
   const LevelConsts lc = level_consts(alpha, -1.0, 1.0, d);
   const unsigned stride = gridDim.x * blockDim.x;
-  for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
-    const size_t i = (size_t)q * 4;
-    const float4 vv = *reinterpret_cast<const float4*>(v + i), ww = *reinterpret_cast<const float4*>(wstar + i),
-                 dd = *reinterpret_cast<const float4*>(dual + i);
-    const float ve[4] = {vv.x, vv.y, vv.z, vv.w}, we[4] = {ww.x, ww.y, ww.z, ww.w}, de[4] = {dd.x, dd.y, dd.z, dd.w};
-    float ge[4], du[4];
-    int ri[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float u = __builtin_fmaf(ve[e], lc.c1, lc.c0);
-      u = fminf(fmaxf(u, 0.0f), lc.lmax);
-      float rf = rintf(u);
-      if (!(fabsf(u - rf) < 0.4998f)) {
-        double r;
-        disc64((double)ve[e], alpha, -1.0, 1.0, d, &r);
-        rf = (float)r;
-      }
-      ri[e] = (int)rf;
-      const float b = (float)((double)rf * d + -1.0);       // disc64's r * d + lo
-      ge[e] = alpha32 * b;
-      float t = (we[e] - ge[e]) + de[e];                    // EfficientQConv.py:111
-      if (dual_div != 1.0f) t = t / dual_div;               // "dual /= 2" or "dual /= rho_m/rho" (:131-136)
-      du[e] = t;
-    }
-    *reinterpret_cast<float4*>(G + i) = make_float4(ge[0], ge[1], ge[2], ge[3]);
-    *reinterpret_cast<float4*>(dual + i) = make_float4(du[0], du[1], du[2], du[3]);
-    if (Gq != nullptr) {
-      char4 c;
-      if (lm1 >= 128) {
-        c = make_char4((signed char)(ri[0] - 128), (signed char)(ri[1] - 128), (signed char)(ri[2] - 128), (signed char)(ri[3] - 128));
-      } else {
-        c = make_char4((signed char)(2 * ri[0] - lm1), (signed char)(2 * ri[1] - lm1), (signed char)(2 * ri[2] - lm1),
-                       (signed char)(2 * ri[3] - lm1));
-      }
-      *reinterpret_cast<char4*>(Gq + i) = c;
-    }
-    if (nx.Bm != nullptr) {                       // right-hand side of the NEXT prox solve (k_build_b4's arithmetic)
-      const unsigned i32 = q * 4u;
-      const unsigned r = i32 / (unsigned)nx.nwrow, k = i32 - r * (unsigned)nx.nwrow;   // a group of 4 never straddles rows
-      const float* bp = nx.B0 + (size_t)r * (size_t)nx.n + k;                            // (rows of B0 are n long: unaligned)
-      const float4 w0 = *reinterpret_cast<const float4*>(nx.W0 + i);
-      const float w0e[4] = {w0.x, w0.y, w0.z, w0.w};
-      float be[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = bp[e] + nx.eta * w0e[e];
-        be[e] = t + nx.rho * (ge[e] - du[e]);
-      }
-      *reinterpret_cast<float4*>(nx.Bm + (size_t)r * (size_t)nx.ldb + k) = make_float4(be[0], be[1], be[2], be[3]);
-    }
-  }
+  for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride)
+    proj4_apply(q, v, wstar, alpha, alpha32, lc, d, G, dual, dual_div, Gq, lm1, nx);
 }
 
 // ---- backward of PTQConv._quantize_act with the straight-through estimator (row f3) ------------------------------------
@@ -1185,15 +1108,28 @@ int effq_fixed_point_sorted(const float* a, const float* b, float* v_out, size_t
   return EFFQ_OK;
 }
 
+int effq_fixed_point_small_fused(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                                 double tol, int max_iter, effq_fp_state* state_dev, const ProjFused* pf_in, void* stream);
+
 int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                            double tol, int max_iter, effq_fp_state* state_dev, void* stream) {
+  return effq_fixed_point_small_fused(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, nullptr, stream);
+}
+
+// internal (admm_run.hip): pf != NULL runs the projection of the ADMM iteration as the kernel's epilogue
+int effq_fixed_point_small_fused(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
+                                 double tol, int max_iter, effq_fp_state* state_dev, const ProjFused* pf_in, void* stream) {
+  ProjFused pf;
+  memset(&pf, 0, sizeof(pf));
+  if (pf_in != nullptr) pf = *pf_in;
+  EFFQ_CHECK_ARG(pf.G == nullptr || v_out != nullptr);
   EFFQ_CHECK_ARG(a && state_dev && n > 0 && levels >= 2 && hi > lo && max_iter > 0);
   EFFQ_CHECK_ARG(n <= effq_fp_small_max());
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
   const double d = (hi - lo) / (double)(levels - 1);
   // many levels on a small tensor: the sorted-value kernel (effq_fixed_point_sorted) where it is the faster one
   static const int sorted_on = getenv("EFFQ_FP_SORTED") ? atoi(getenv("EFFQ_FP_SORTED")) : 0;   // A/B switch
-  if (sorted_on && levels >= 32 && levels <= 256 && n <= (size_t)FPSORT_MAXN)
+  if (sorted_on && pf.G == nullptr && levels >= 32 && levels <= 256 && n <= (size_t)FPSORT_MAXN)
     return effq_fixed_point_sorted(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, stream);
   {
     // threads: 256 up to 2048 elements, 512 up to 16384 (few waves: the barrier is cheap and the element loop stays
@@ -1207,7 +1143,7 @@ int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t 
     while (pp < per) pp <<= 1;
     hipStream_t st = as_stream(stream);
 #define EFFQ_FPS(TT, PP)                                                                                          \
-  hipLaunchKernelGGL((k_fp_small<TT, PP>), dim3(1), dim3(TT), 0, st, a, b, v_out, n, state_dev, lo, hi, d, tol, max_iter)
+  hipLaunchKernelGGL((k_fp_small<TT, PP>), dim3(1), dim3(TT), 0, st, a, b, v_out, n, state_dev, lo, hi, d, tol, max_iter, pf)
     if (T == 256) {
       switch (pp) {
         case 1: EFFQ_FPS(256, 1); break;
