@@ -61,17 +61,18 @@ __global__ __launch_bounds__(256) void k_pack_weight_i8(const int8_t* __restrict
 
 // Packed layout for the wide-channel kernel: [tap][group g][k-half h][c2p][16 bytes], so that the B operand of one
 // MFMA is a 512-byte contiguous run per lane half (coalesced 16-byte loads straight from L2).
+template <int RPW>      // output channels per workgroup: 4 = 64-byte store runs, 1 = four times as many workgroups
 __global__ __launch_bounds__(256) void k_pack_weight_i8g(const int8_t* __restrict__ Gq, int8_t* __restrict__ wq, int C1,
                                                          int C2, int T, int c2p) {
-  // One workgroup = 4 output channels: their rows of Gq ([C1][T] bytes each, contiguous) are read coalesced into LDS,
-  // then every thread assembles 16-byte cells (tap, g, h, j) from bytes T apart in LDS and stores them - the 4 channels
-  // of a (tap, g, h) are 64 contiguous bytes.  (One thread per cell gathering its 16 bytes from global memory, T bytes
-  // apart, took 43-69 us per call in situ for 1.77 MB of weights.)
-  extern __shared__ __attribute__((aligned(16))) int8_t rows[];          // [4][C1 * T]
+  // One workgroup = RPW output channels: their rows of Gq ([C1][T] bytes each, contiguous) are read coalesced into LDS,
+  // then every thread assembles 16-byte cells (tap, g, h, j) from bytes T apart in LDS and stores them - with RPW = 4 the
+  // 4 channels of a (tap, g, h) are 64 contiguous bytes.  (One thread per cell gathering its 16 bytes from global memory,
+  // T bytes apart, took 43-69 us per call in situ for 1.77 MB of weights.)
+  extern __shared__ __attribute__((aligned(16))) int8_t rows[];          // [RPW][C1 * T]
   const int rowb = C1 * T;
-  const int j0 = blockIdx.x * 4;
+  const int j0 = blockIdx.x * RPW;
   const int rowv = rowb / 16;                      // C1 % 16 == 0: rows are whole 16-byte vectors
-  for (int e = threadIdx.x; e < 4 * rowv; e += 256) {
+  for (int e = threadIdx.x; e < RPW * rowv; e += 256) {
     const int jj = e / rowv, o = e - jj * rowv;
     v4i val = {0, 0, 0, 0};
     if (j0 + jj < C2) val = *reinterpret_cast<const v4i*>(Gq + (size_t)(j0 + jj) * rowb + (size_t)o * 16);
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(256) void k_pack_weight_i8g(const int8_t* __restric
   }
   __syncthreads();
   const int ncell = T * (C1 / 16);                                       // cells per output channel
-  for (int u = threadIdx.x; u < ncell * 4; u += 256) {
-    const int jj = u & 3, q = u >> 2;
+  for (int u = threadIdx.x; u < ncell * RPW; u += 256) {
+    const int jj = u % RPW, q = u / RPW;
     const int gh = q % (C1 / 16), tap = q / (C1 / 16);
     if (j0 + jj >= c2p) continue;
     const int8_t* src = rows + jj * rowb + (16 * gh) * T + tap;
@@ -1150,7 +1151,7 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
   if (p.C1 == 64 && p.C2 == 64 && !w64_off && !i8_stream64() && p.OD % ITD == 0 && p.OH % ITH == 0 && p.OW % ITW == 0) {
     size_t nb = (pl.wq_bytes + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_pack_weight_i8g, dim3((unsigned)((p.c2p + 3) / 4)), dim3(256), (size_t)4 * p.C1 * 27, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
+    hipLaunchKernelGGL(k_pack_weight_i8g<4>, dim3((unsigned)((p.c2p + 3) / 4)), dim3(256), (size_t)4 * p.C1 * 27, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
     const size_t lds = (size_t)W64_WLB + W64_HALOB;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1170,8 +1171,15 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
     if (nb > 2048) nb = 2048;
     if (p.C1 < 64 || (p.C1 == 64 && !i8_stream64()))
       hipLaunchKernelGGL(k_pack_weight_i8, dim3((unsigned)nb), dim3(256), 0, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
-    else
-      hipLaunchKernelGGL(k_pack_weight_i8g, dim3((unsigned)((p.c2p + 3) / 4)), dim3(256), (size_t)4 * p.C1 * 27, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
+    else {
+      // the pack sits on the loss stream beside the ADMM chain: one output channel per workgroup (128 - 512 workgroups
+      // instead of 32 - 128) shortens it.  EFFQ_I8_PACK_RPW=4: the 4-channel form (A/B switch)
+      static const int rpw = getenv("EFFQ_I8_PACK_RPW") ? atoi(getenv("EFFQ_I8_PACK_RPW")) : 1;
+      if (rpw == 4)
+        hipLaunchKernelGGL(k_pack_weight_i8g<4>, dim3((unsigned)((p.c2p + 3) / 4)), dim3(256), (size_t)4 * p.C1 * 27, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
+      else
+        hipLaunchKernelGGL(k_pack_weight_i8g<1>, dim3((unsigned)p.c2p), dim3(256), (size_t)p.C1 * 27, st, Gq, wq, p.C1, p.C2, 27, p.c2p);
+    }
     EFFQ_LAUNCH_CHECK();
   }
   if (p.C1 == 32) {
