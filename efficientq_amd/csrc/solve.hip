@@ -7,6 +7,7 @@
 // blocked in-place Gauss-Jordan sweep (no pivoting needed for SPD) whose bulk is a rank-64 fp64
 // MFMA update (v_mfma_f64_16x16x4_f64), then rounded once to fp32.
 #include <cstdlib>
+#include <vector>
 #include "common.h"
 
 namespace effq {
@@ -332,6 +333,249 @@ __global__ __launch_bounds__(256) void k_a64_to_f32(const double* __restrict__ A
     // only the upper block triangle is maintained (symmetric Gauss-Jordan): mirror it.  Columns >= n are padding.
     const int a = (i < j) ? i : j, b = (i < j) ? j : i;
     Ainv[e] = (j < n) ? (float)A64[(size_t)a * npad + b] : 0.0f;
+  }
+}
+
+// ======================================================================================================================
+// The same symmetric block Gauss-Jordan with pivot blocks of 256 rows (WB = 4 of the 64-blocks above).
+//
+// The rank-64 sweep reads and writes the stored triangle once per 64 columns: 8 flop per byte moved, an HBM / Infinity-
+// Cache stream that left the fp64 matrix cores at a third of their rate (n = 6913: 12.9 ms alone, 27 - 33 ms beside the
+// ADMM chain).  With a 256-row pivot block P the elimination step is the same algebra on bigger blocks,
+//   X_t = M_tP (t outside P),  Z_t = X_t inv(M_PP),  M_ij -= Z_i (s_j X_j^T),  new M_tP = -+Z_t,  new M_PP = inv(M_PP),
+// and the update of the triangle is a rank-256 product: 32 flop per byte of C, four times fewer passes over the matrix.
+// Per pivot block:
+//   k_gj_panel_w   Z = X inv(M_PP) for every 64-row block outside P -> the operands of the update, both K-major
+//                  (NZT = -Z^T, XTW = s X^T: [256][ldx]), nothing written to the matrix yet (the workgroups of one block
+//                  row read each other's blocks);
+//   k_gj_wback_w   the new pivot rows / columns and inv(M_PP) into the matrix;
+//   k_gj_big       the update, 128 x 128 tiles of the upper triangle, K = 256 staged through LDS in chunks of 16;
+//   the NEXT pivot block: k_gj_big on its own 256 x 256 tile alone (out of place, into the scratch matrix D), the rank-64
+//                  sweep above on D (a 256 x 256 matrix of its own), k_mirror_blocks.  None of that depends on the big
+//                  update, which leaves that tile alone: it runs on a helper stream BESIDE the big update, so the serial
+//                  pivot work (4 x 64 dependent pivots per pivot block) is off the critical path for n >= ~5000.
+constexpr int WB = 4, WK = WB * NBK;
+constexpr int BG_T = 128, BG_KC = 16, BG_LD = 144;      // macro tile, K chunk, LDS row pitch (doubles): see the bank notes below
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+struct GjBig {
+  const double* Cin;      // the matrix, addressed in place: block (i, j) at Cin[(i*64)*ldin + j*64]
+  size_t ldin;
+  double* Cout;           // output: Cout[(i*64 - orow)*ldout + (j*64 - ocol)]  (Cin itself for the in-place update)
+  size_t ldout;
+  int orow, ocol;
+  const double* NZT;      // [kdim][ldx]: -Z^T  (A operand, K-major)
+  const double* XTW;      // [kdim][ldx]: s X^T (B operand)
+  size_t ldx;
+  int kdim;               // 64 * (64-blocks of the pivot); 0 = plain copy
+  int nblk;               // 64-blocks per side
+  int i0m, j0m;           // macro-tile offset of the grid
+  int skip_lo, skip_hi;   // 64-blocks of the pivot: rows / columns left alone
+  int la_lo, la_hi;       // 64-blocks of the NEXT pivot: blocks with BOTH indices inside are left alone
+};
+
+// One 128 x 128 macro tile per workgroup, one 64 x 64 block per wave (16 accumulator tiles of 16 x 16), K in chunks of 16
+// through a double-buffered LDS stage: global -> registers (issued before the MFMAs of the current chunk) -> LDS, one
+// barrier per chunk.  Both operands are K-major ([k][row]): an operand fetch is one ds_read_b64 per lane, lanes 0-15 /
+// 16-31 of a half-wave read rows k and k+1, 144 doubles = 32 banks (mod 64) apart: conflict-free; the staging stores
+// are ds_write_b128 with the 8 lanes of a group 16 B apart.  64 MFMAs (64 cycles each) per wave and chunk against 32
+// operand reads and 4 + 4 staging stores: the kernel is paced by the matrix pipe, and by its C traffic (16 B per 512 flop).
+__global__ __launch_bounds__(256, 2) void k_gj_big(const GjBig p) {
+  __shared__ __attribute__((aligned(16))) double As[2][BG_KC * BG_LD];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BG_KC * BG_LD];
+  const int I = p.i0m + (int)blockIdx.y, J = p.j0m + (int)blockIdx.x;
+  if (J < I) return;
+  auto blk_live = [&](int bi, int bj) -> bool {
+    if (bi > bj || bj >= p.nblk) return false;
+    if ((bi >= p.skip_lo && bi < p.skip_hi) || (bj >= p.skip_lo && bj < p.skip_hi)) return false;
+    if (bi >= p.la_lo && bi < p.la_hi && bj >= p.la_lo && bj < p.la_hi) return false;
+    return true;
+  };
+  if (!(blk_live(2 * I, 2 * J) || blk_live(2 * I, 2 * J + 1) || blk_live(2 * I + 1, 2 * J) || blk_live(2 * I + 1, 2 * J + 1)))
+    return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int bi = 2 * I + wr, bj = 2 * J + wc;
+  const bool live = blk_live(bi, bj);
+  f64x4 acc[4][4];
+  if (live) {
+    const double* Cb = p.Cin + (size_t)bi * NBK * p.ldin + (size_t)bj * NBK;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = Cb[(size_t)(mi * 16 + lk + 4 * r) * p.ldin + ni * 16 + lr];
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0;
+  }
+  const int nch = p.kdim / BG_KC;
+  if (nch > 0) {
+    const int sk = tid >> 4, sc = (tid & 15) * 2;       // staging: K row, first column (doubles) of the 4 pieces 32 apart
+    const double* Ag = p.NZT + (size_t)sk * p.ldx + (size_t)I * BG_T + sc;
+    const double* Bg = p.XTW + (size_t)sk * p.ldx + (size_t)J * BG_T + sc;
+    f64x2 ra[4], rb[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      ra[v] = *reinterpret_cast<const f64x2*>(Ag + v * 32);
+      rb[v] = *reinterpret_cast<const f64x2*>(Bg + v * 32);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      *reinterpret_cast<f64x2*>(&As[0][sk * BG_LD + sc + v * 32]) = ra[v];
+      *reinterpret_cast<f64x2*>(&Bs[0][sk * BG_LD + sc + v * 32]) = rb[v];
+    }
+    lds_barrier();
+    for (int c = 0; c < nch; ++c) {
+      const int buf = c & 1;
+      if (c + 1 < nch) {
+        const size_t off = (size_t)(c + 1) * BG_KC * p.ldx;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          ra[v] = *reinterpret_cast<const f64x2*>(Ag + off + v * 32);
+          rb[v] = *reinterpret_cast<const f64x2*>(Bg + off + v * 32);
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int ks = 0; ks < BG_KC / 4; ++ks) {
+          double a[4], b[4];
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) a[mi] = As[buf][(ks * 4 + lk) * BG_LD + wr * 64 + mi * 16 + lr];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) b[ni] = Bs[buf][(ks * 4 + lk) * BG_LD + wc * 64 + ni * 16 + lr];
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+      }
+      if (c + 1 < nch) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          *reinterpret_cast<f64x2*>(&As[buf ^ 1][sk * BG_LD + sc + v * 32]) = ra[v];
+          *reinterpret_cast<f64x2*>(&Bs[buf ^ 1][sk * BG_LD + sc + v * 32]) = rb[v];
+        }
+      }
+      lds_barrier();
+    }
+  }
+  if (live) {
+    double* Ob = p.Cout + ((size_t)bi * NBK - p.orow) * p.ldout + ((size_t)bj * NBK - p.ocol);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ob[(size_t)(mi * 16 + lk + 4 * r) * p.ldout + ni * 16 + lr] = acc[mi][ni][r];
+  }
+}
+
+// Z_t[:, c] = sum_a X_t[:, a] * Dw[a, c] for the 64-row block t outside the pivot (blocks kb0 .. kb0 + m - 1) and the
+// pivot's column block c; Dw = the full symmetric inverse of the pivot block ([64 m][64 m]).  Writes only the operand
+// panels: XTW[c*64 + kk][t*64 + r] = s X[r][c*64 + kk], NZT[c*64 + col][t*64 + row] = -Z[row][col].
+__global__ __launch_bounds__(256) void k_gj_panel_w(const double* __restrict__ A, int npad, int kb0, int m,
+                                                    const double* __restrict__ Dw, double* __restrict__ NZT,
+                                                    double* __restrict__ XTW, size_t ldx) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* As = sm;                  // X_t[:, a]  [64][LDA_S]
+  double* Bs = sm + NBK * LDA_S;    // Dw[a, c]   [64][LDB_S]
+  const int t = blockIdx.x, c = blockIdx.y;
+  if (t >= kb0 && t < kb0 + m) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const bool upper = t < kb0;
+  const double sgn = upper ? -1.0 : 1.0;
+  const int ldd = m * NBK;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0;
+  for (int a = 0; a < m; ++a) {
+    for (int e = tid; e < NBK * NBK; e += 256) {
+      const int r = e >> 6, cc = e & 63;
+      if (upper)
+        As[r * LDA_S + cc] = A[(size_t)(t * NBK + r) * npad + (size_t)(kb0 + a) * NBK + cc];       // X[r][cc]
+      else
+        As[cc * LDA_S + r] = A[(size_t)((kb0 + a) * NBK + r) * npad + (size_t)t * NBK + cc];       // X[cc][r]
+    }
+    load_tile(Bs, LDB_S, Dw + (size_t)a * NBK * ldd + (size_t)c * NBK, (size_t)ldd);
+    lds_barrier();
+    if (a == c)
+      for (int e = tid; e < NBK * NBK; e += 256) {
+        const int kk = e >> 6, r = e & 63;
+        XTW[(size_t)(c * NBK + kk) * ldx + (size_t)t * NBK + r] = sgn * As[r * LDA_S + kk];
+      }
+    tile_mma64(As, Bs, acc);
+    lds_barrier();
+  }
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        As[(wr * 32 + mi * 16 + lk + 4 * r) * LDA_S + wc * 32 + ni * 16 + lr] = acc[mi][ni][r];     // Z[row][col]
+  lds_barrier();
+  for (int e = tid; e < NBK * NBK; e += 256) {
+    const int kk = e >> 6, r = e & 63;
+    NZT[(size_t)(c * NBK + kk) * ldx + (size_t)t * NBK + r] = -As[r * LDA_S + kk];
+  }
+}
+
+// The pivot rows / columns after the step: block (t, kb0 + c) = -Z_t[:, c] for t above the pivot, block (kb0 + c, t) =
+// Z_t[:, c]^T for t below it, and the pivot block itself = Dw (upper 64-blocks).
+__global__ __launch_bounds__(256) void k_gj_wback_w(double* __restrict__ A, int npad, int kb0, int m,
+                                                    const double* __restrict__ Dw, const double* __restrict__ NZT,
+                                                    size_t ldx) {
+  __shared__ double Ts[NBK * (NBK + 1)];
+  const int t = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const int ldd = m * NBK;
+  if (t >= kb0 && t < kb0 + m) {
+    const int a = t - kb0;
+    if (a > c) return;
+    for (int e = tid; e < NBK * NBK; e += 256) {
+      const int r = e >> 6, cc = e & 63;
+      A[(size_t)(t * NBK + r) * npad + (size_t)(kb0 + c) * NBK + cc] = Dw[(size_t)(a * NBK + r) * ldd + (size_t)c * NBK + cc];
+    }
+    return;
+  }
+  if (t < kb0) {
+    for (int e = tid; e < NBK * NBK; e += 256) {
+      const int kk = e >> 6, r = e & 63;
+      Ts[kk * (NBK + 1) + r] = NZT[(size_t)(c * NBK + kk) * ldx + (size_t)t * NBK + r];      // -Z[r][kk]
+    }
+    __syncthreads();
+    for (int e = tid; e < NBK * NBK; e += 256) {
+      const int r = e >> 6, kk = e & 63;
+      A[(size_t)(t * NBK + r) * npad + (size_t)(kb0 + c) * NBK + kk] = Ts[kk * (NBK + 1) + r];
+    }
+  } else {
+    for (int e = tid; e < NBK * NBK; e += 256) {
+      const int kk = e >> 6, r = e & 63;
+      A[(size_t)((kb0 + c) * NBK + kk) * npad + (size_t)t * NBK + r] = -NZT[(size_t)(c * NBK + kk) * ldx + (size_t)t * NBK + r];
+    }
+  }
+}
+
+// the rank-64 sweep keeps the upper 64-block triangle: fill in the blocks below the diagonal (the finished inverse is
+// symmetric)
+__global__ __launch_bounds__(256) void k_mirror_blocks(double* __restrict__ D, int nd) {
+  const size_t tot = (size_t)nd * nd;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / nd), j = (int)(e % nd);
+    if ((i / NBK) > (j / NBK)) D[e] = D[(size_t)j * nd + i];
   }
 }
 
@@ -793,41 +1037,36 @@ using namespace effq;
 
 extern "C" {
 
+// workspace of the rank-64 sweep on an npad x npad matrix that is already in place: XT [64][npad], NZ [npad][64], 2 Dinv
+static size_t gj64_aux_doubles(size_t npad) { return 2 * (size_t)NBK * npad + 2 * NBK * NBK; }
+
+// the wide sweep (pivot blocks of 256) from this many 64-blocks on; EFFQ_GJ_WIDE=0: the rank-64 sweep everywhere (A/B)
+static int gj_wide_min_blocks() {
+  static const int off = getenv("EFFQ_GJ_WIDE") != nullptr && atoi(getenv("EFFQ_GJ_WIDE")) == 0;
+  static const int mn = getenv("EFFQ_GJ_WIDE_MIN") ? atoi(getenv("EFFQ_GJ_WIDE_MIN")) : 2 * WB;
+  return off ? (1 << 30) : mn;
+}
+
 size_t effq_spd_inverse_ws_bytes(int n) {
   if (n <= 0) return 0;
   const size_t npad = (size_t)round_up(n, NBK);
-  return npad * npad * sizeof(double) + 2 * (size_t)NBK * npad * sizeof(double) + 2 * NBK * NBK * sizeof(double) + 256;
+  size_t d = npad * npad + gj64_aux_doubles(npad);
+  if ((int)(npad / NBK) >= gj_wide_min_blocks()) {
+    const size_t ldx = (size_t)round_up((int)npad, BG_T);
+    d = npad * npad + 2 * (size_t)WK * ldx + (size_t)WK * WK + gj64_aux_doubles(WK);
+  }
+  return d * sizeof(double) + 256;
 }
 
 int effq_ainv_ld(int n) { return n > 0 ? round_up(n, 32) : 0; }
 
-int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double eta, float* Ainv, void* ws,
-                     size_t ws_bytes, void* stream) {
-  EFFQ_CHECK_ARG(A0 && Ainv && ws && n > 0);
-  EFFQ_CHECK_ARG(eta > 0.0 && rho >= 0.0);
-  if (ws_bytes < effq_spd_inverse_ws_bytes(n)) {
-    set_error("spd_inverse: workspace %zu < required %zu", ws_bytes, effq_spd_inverse_ws_bytes(n));
-    return EFFQ_ERR_WORKSPACE;
-  }
-  const int npad = round_up(n, NBK);
+// in-place rank-64 symmetric Gauss-Jordan sweep of the npad x npad matrix A64 (upper 64-block triangle kept)
+static int gj64_sweep(double* A64, int npad, double* aux, hipStream_t st) {
   const int nblk = npad / NBK;
-  double* A64 = reinterpret_cast<double*>(ws);
-  double* XT = A64 + (size_t)npad * npad;        // [64][npad]
+  double* XT = aux;                              // [64][npad]
   double* NZ = XT + (size_t)NBK * npad;          // [npad][64]
   double* Dinv = NZ + (size_t)NBK * npad;
-  hipStream_t st = as_stream(stream);
-  {
-    size_t nb = ((size_t)npad * npad + 255) / 256;
-    if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(k_build_a64, dim3((unsigned)nb), dim3(256), 0, st, A0, n, npad, has_bias, rho, eta, A64);
-    EFFQ_LAUNCH_CHECK();
-  }
   const size_t lds = (size_t)(NBK * LDA_S + NBK * LDB_S) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   // The trailing update of step k also forms the inverse of the NEXT pivot block (look-ahead workgroup, see
   // k_gj_trail_sym): only step 0 needs the stand-alone k_gj_diag.  Dinv is double-buffered by step parity.
   static const bool ahead_off = getenv("EFFQ_GJ_AHEAD") != nullptr && atoi(getenv("EFFQ_GJ_AHEAD")) == 0;   // A/B switch
@@ -842,6 +1081,138 @@ int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double et
                          XT, ahead_off ? (double*)nullptr : Dn);
     EFFQ_LAUNCH_CHECK();
   }
+  return EFFQ_OK;
+}
+
+// helper stream + two events per (thread, caller stream): the next pivot block is inverted beside the big update
+struct GjWideCtx {
+  int dev;
+  hipStream_t caller, helper;
+  hipEvent_t e1, e2;
+};
+static thread_local std::vector<GjWideCtx> g_gj_ctx;
+
+static int gj_wide_ctx(hipStream_t caller, GjWideCtx** out) {
+  int dev = 0;
+  EFFQ_HIP(hipGetDevice(&dev));
+  for (GjWideCtx& c : g_gj_ctx)
+    if (c.dev == dev && c.caller == caller) {
+      *out = &c;
+      return EFFQ_OK;
+    }
+  GjWideCtx c;
+  c.dev = dev;
+  c.caller = caller;
+  int prio = 0;
+  if (hipStreamGetPriority(caller, &prio) != hipSuccess) prio = 0;
+  EFFQ_HIP(hipStreamCreateWithPriority(&c.helper, hipStreamNonBlocking, prio));
+  EFFQ_HIP(hipEventCreateWithFlags(&c.e1, hipEventDisableTiming));
+  EFFQ_HIP(hipEventCreateWithFlags(&c.e2, hipEventDisableTiming));
+  g_gj_ctx.push_back(c);
+  *out = &g_gj_ctx.back();
+  return EFFQ_OK;
+}
+
+static int gj_wide_sweep(double* A64, int npad, double* aux, hipStream_t st) {
+  const int nblk = npad / NBK;
+  const size_t ldx = (size_t)round_up(npad, BG_T);
+  double* NZT = aux;                               // [256][ldx]
+  double* XTW = NZT + (size_t)WK * ldx;            // [256][ldx]
+  double* Dw = XTW + (size_t)WK * ldx;             // [64 m][64 m]: the pivot block, then its inverse
+  double* aux64 = Dw + (size_t)WK * WK;
+  const int nK = (nblk + WB - 1) / WB, nm = (nblk + 1) / 2;
+  static const bool overlap_on = !(getenv("EFFQ_GJ_OVERLAP") != nullptr && atoi(getenv("EFFQ_GJ_OVERLAP")) == 0);   // A/B
+  GjWideCtx* ctx = nullptr;
+  if (overlap_on && nK > 1) {
+    const int rc = gj_wide_ctx(st, &ctx);
+    if (rc != EFFQ_OK) return rc;
+  }
+  hipStream_t s2 = ctx ? ctx->helper : st;
+  const size_t lds = (size_t)(NBK * LDA_S + NBK * LDB_S) * sizeof(double);
+  auto pivot_block = [&](int k0, int mk, int kdim, hipStream_t s) -> int {
+    // Dw = the pivot block (blocks k0 .. k0 + mk - 1) with the pending rank-kdim update applied, then inverted
+    GjBig g;
+    memset(&g, 0, sizeof(g));
+    g.Cin = A64; g.ldin = (size_t)npad;
+    g.Cout = Dw; g.ldout = (size_t)mk * NBK; g.orow = k0 * NBK; g.ocol = k0 * NBK;
+    g.NZT = NZT; g.XTW = XTW; g.ldx = ldx; g.kdim = kdim; g.nblk = nblk;
+    g.i0m = k0 / 2; g.j0m = k0 / 2;
+    g.skip_lo = g.skip_hi = -1; g.la_lo = g.la_hi = -1;
+    const int span = (mk + 1) / 2;
+    hipLaunchKernelGGL(k_gj_big, dim3(span, span), dim3(256), 0, s, g);
+    EFFQ_LAUNCH_CHECK();
+    const int rc = gj64_sweep(Dw, mk * NBK, aux64, s);
+    if (rc != EFFQ_OK) return rc;
+    hipLaunchKernelGGL(k_mirror_blocks, dim3(64), dim3(256), 0, s, Dw, mk * NBK);
+    EFFQ_LAUNCH_CHECK();
+    return EFFQ_OK;
+  };
+  {
+    const int rc = pivot_block(0, nblk < WB ? nblk : WB, 0, st);
+    if (rc != EFFQ_OK) return rc;
+  }
+  for (int K = 0; K < nK; ++K) {
+    const int kb0 = K * WB, m = (nblk - kb0 < WB) ? nblk - kb0 : WB;
+    const int kn0 = kb0 + WB, mn = (K + 1 < nK) ? ((nblk - kn0 < WB) ? nblk - kn0 : WB) : 0;
+    hipLaunchKernelGGL(k_gj_panel_w, dim3(nblk, m), dim3(256), lds, st, A64, npad, kb0, m, Dw, NZT, XTW, ldx);
+    EFFQ_LAUNCH_CHECK();
+    if (ctx) {
+      EFFQ_HIP(hipEventRecord(ctx->e1, st));
+      EFFQ_HIP(hipStreamWaitEvent(s2, ctx->e1, 0));
+    }
+    hipLaunchKernelGGL(k_gj_wback_w, dim3(nblk, m), dim3(256), 0, s2, A64, npad, kb0, m, Dw, NZT, ldx);
+    EFFQ_LAUNCH_CHECK();
+    if (mn > 0) {
+      const int rc = pivot_block(kn0, mn, m * NBK, s2);
+      if (rc != EFFQ_OK) return rc;
+    }
+    if (nblk > m) {
+      GjBig g;
+      memset(&g, 0, sizeof(g));
+      g.Cin = A64; g.ldin = (size_t)npad;
+      g.Cout = A64; g.ldout = (size_t)npad; g.orow = 0; g.ocol = 0;
+      g.NZT = NZT; g.XTW = XTW; g.ldx = ldx; g.kdim = m * NBK; g.nblk = nblk;
+      g.i0m = 0; g.j0m = 0;
+      g.skip_lo = kb0; g.skip_hi = kb0 + m;
+      g.la_lo = mn > 0 ? kn0 : -1; g.la_hi = mn > 0 ? kn0 + mn : -1;
+      hipLaunchKernelGGL(k_gj_big, dim3(nm, nm), dim3(256), 0, st, g);
+      EFFQ_LAUNCH_CHECK();
+    }
+    if (ctx) {
+      EFFQ_HIP(hipEventRecord(ctx->e2, s2));
+      EFFQ_HIP(hipStreamWaitEvent(st, ctx->e2, 0));
+    }
+  }
+  return EFFQ_OK;
+}
+
+int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double eta, float* Ainv, void* ws,
+                     size_t ws_bytes, void* stream) {
+  EFFQ_CHECK_ARG(A0 && Ainv && ws && n > 0);
+  EFFQ_CHECK_ARG(eta > 0.0 && rho >= 0.0);
+  if (ws_bytes < effq_spd_inverse_ws_bytes(n)) {
+    set_error("spd_inverse: workspace %zu < required %zu", ws_bytes, effq_spd_inverse_ws_bytes(n));
+    return EFFQ_ERR_WORKSPACE;
+  }
+  const int npad = round_up(n, NBK);
+  double* A64 = reinterpret_cast<double*>(ws);
+  double* aux = A64 + (size_t)npad * npad;
+  hipStream_t st = as_stream(stream);
+  {
+    size_t nb = ((size_t)npad * npad + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_build_a64, dim3((unsigned)nb), dim3(256), 0, st, A0, n, npad, has_bias, rho, eta, A64);
+    EFFQ_LAUNCH_CHECK();
+  }
+  const size_t lds = (size_t)(NBK * LDA_S + NBK * LDB_S) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_panel_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int rc = (npad / NBK >= gj_wide_min_blocks()) ? gj_wide_sweep(A64, npad, aux, st) : gj64_sweep(A64, npad, aux, st);
+  if (rc != EFFQ_OK) return rc;
   {
     const int lda = effq_ainv_ld(n);
     size_t nb = ((size_t)n * lda + 255) / 256;

@@ -8,7 +8,8 @@ The reference is imported read-only (``sys.dont_write_bytecode``); its one
 missing dependency on the orchestrator path, ``nibabel``, is replaced by a
 no-op stand-in module.  Only inputs and outputs (data)
 are written; no reference source travels.  Fixtures: G1..G10 of SURVEY.md 8(c), G11 for row f1, G12 for row f3,
-g5b / g5d (wide layers: reference self-spread and the fp64 anchor), g6c / g6d (GPU hook behaviour; wide whole nets).
+g5b / g5d (wide layers: reference self-spread and the fp64 anchor), g5e (a 32 -> 32 layer on V >> n voxels), g6c / g6d (GPU hook
+behaviour; wide whole nets), g6e (LiTS init_stride 2,2,1), g6f (whole nets at 16 / 16 levels).
 With no arguments EVERY fixture is regenerated.
 """
 import argparse
@@ -161,28 +162,38 @@ def g3_g4():
 
 
 # ---------------------------------------------------------------- G5 one layer ptq
-def run_layer(c1, c2, k, stride, pad, N, S, L_w, L_a, q_act, seed, with_mask, bias=True, iters=None):
+def run_layer(c1, c2, k, stride, pad, N, S, L_w, L_a, q_act, seed, with_mask, bias=True, iters=None, inputs=None):
     """iters: run only the first `iters` ADMM iterations (lwq_iter is an instance attribute, EfficientQConv.py:23);
-    the loss history then has `iters` entries and rec["wstar0"/"bstar0"] hold the FIRST proximal solve."""
+    the loss history then has `iters` entries and rec["wstar0"/"bstar0"] hold the FIRST proximal solve.
+    inputs: dict(w, b, x_fp, x, y, mask) built elsewhere (tests/golden_inputs.py) instead of drawn here."""
     gen = torch.Generator().manual_seed(seed)
     conv = models.EfficientQConv(c1, c2, k, stride, pad, 1, 1, bias, q_weight=True, qlvl=L_w,
                                  q_act=q_act, qlvl_act=L_a)
     if iters is not None:
         conv.lwq_iter = int(iters)
-    with torch.no_grad():
-        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (1.0 / (c1 * k ** 3) ** 0.5))
-        if bias:
-            conv.bias.copy_(torch.randn(c2, generator=gen) * 0.1)
-    x_fp = relu_gauss(gen, N, c1, S, S, S)
-    conv.set_fp()
-    y = conv(x_fp).detach()
-    # quantised-upstream stand-in: perturbed input (quirk Q9)
-    x = torch.relu(x_fp + 0.05 * torch.randn(x_fp.shape, generator=gen))
+    if inputs is not None:
+        with torch.no_grad():
+            conv.weight.copy_(inputs["w"])
+            conv.bias.copy_(inputs["b"])
+        conv.set_fp()
+        y = conv(inputs["x_fp"]).detach()
+        assert torch.equal(y, inputs["y"]), "the FP target is exact by construction: every conv returns the same bits"
+        x = inputs["x"].clone()
+    else:
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (1.0 / (c1 * k ** 3) ** 0.5))
+            if bias:
+                conv.bias.copy_(torch.randn(c2, generator=gen) * 0.1)
+        x_fp = relu_gauss(gen, N, c1, S, S, S)
+        conv.set_fp()
+        y = conv(x_fp).detach()
+        # quantised-upstream stand-in: perturbed input (quirk Q9)
+        x = torch.relu(x_fp + 0.05 * torch.randn(x_fp.shape, generator=gen))
     conv.output_fp = y
     conv.name = f"layer_c{c1}_{c2}_k{k}"
     conv.layer_loss = []
     if with_mask:
-        m_full = torch.randint(1, 4, y[:, 0].shape, generator=gen).float()
+        m_full = inputs["mask"].clone() if inputs is not None else torch.randint(1, 4, y[:, 0].shape, generator=gen).float()
         m_half = torch.ones(N, *[d // 2 for d in y.shape[2:]])
         conv.mask_pyramid = [m_half, m_full]
     w_in, b_in = conv.weight.data.clone(), (conv.bias.data.clone() if bias else None)
@@ -374,7 +385,85 @@ def g5d():
     save("g5d_wide_fp64_anchor.npz", **out)
 
 
+def g5e():
+    """The regime the bench runs in: ONE 32 -> 32 3^3 layer calibrated by the reference on
+    V >> n voxels - one 1 x 32 x 32^3 and one 1 x 32 x 48^3 volume (V / n = 38 and 128; g5b: 4), with an attention mask, with 1
+    and with 8 BLAS threads, plus the oracle's fp64 evaluation of the same arithmetic.  The tensors are rebuilt from a
+    seed by tests/golden_inputs.py (the FP target is exact in fp32 by construction); the fixture keeps their checksums,
+    what the reference produced, and the reference's own t1-vs-t8 distances."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import effq_oracle as O
+    from tests import golden_inputs as GI
+    out = {}
+    for tag, case in GI.G5E_CASES.items():
+        S = case["S"]
+        inp = GI.wide_layer_inputs(S, case["seed"])
+        y64 = F.conv3d(inp["x_fp"].double(), inp["w"].double(), inp["b"].double(), 1, 1)
+        assert torch.equal(inp["y"].double(), y64), "target exact in fp32"
+        kw = dict(c1=32, c2=32, k=3, stride=1, pad=1, N=1, S=S, L_w=4, L_a=4, q_act=True, seed=case["seed"],
+                  with_mask=True, inputs=inp)
+        recs = {}
+        for nt in (1, 8):
+            torch.set_num_threads(nt)
+            recs[nt] = run_layer(**kw)
+        torch.set_num_threads(8)
+        out[f"{tag}_meta"] = recs[8]["meta"]
+        out[f"{tag}_seed"] = np.int64(case["seed"])
+        for k in ("w", "b", "x", "y", "mask"):
+            out[f"{tag}_chk_{k}"] = GI.checksums(inp[k])
+        out[f"{tag}_x_sub"] = inp["x"][:, ::8, ::8, ::8, ::8]
+        out[f"{tag}_y_sub"] = inp["y"][:, ::8, ::8, ::8, ::8]
+        sub = 4
+        for nt, rec in recs.items():
+            assert torch.equal(rec["x"], inp["x"]) and torch.equal(rec["y"], inp["y"])
+            fq = rec["fwd_q"]
+            out[f"{tag}_t{nt}_fwd_q_sub"] = fq[:, :, ::sub, ::sub, ::sub].contiguous()
+            out[f"{tag}_t{nt}_fwd_q_chk"] = GI.checksums(fq)
+            for k in ("loss_hist", "final_mse", "aw_hist", "weight", "bias", "alpha_w", "alpha_act", "layer_loss",
+                      "wstar0", "bstar0", "G0idx"):
+                out[f"{tag}_t{nt}_{k}"] = rec[k]
+        out[f"{tag}_fwd_sub"] = np.int64(sub)
+        a, b = recs[1], recs[8]
+        L = 4
+        lv = lambda t: torch.round((t / t.abs().max() + 1) * (L - 1) / 2)
+        spread = dict(
+            layer_loss=abs(a["layer_loss"] - b["layer_loss"]) / b["layer_loss"],
+            best_mse=abs(a["loss_hist"].min() - b["loss_hist"].min()) / b["loss_hist"].min(),
+            idx_mismatch=(lv(a["weight"]) != lv(b["weight"])).float().mean().item(),
+            out_rel_mse=(((a["fwd_q"] - b["fwd_q"]) ** 2).mean() / (b["fwd_q"] ** 2).mean()).item(),
+            hist_max=float(np.max(np.abs(a["loss_hist"] - b["loss_hist"]) / b["loss_hist"])))
+        for k, v in spread.items():
+            out[f"{tag}_spread_{k}"] = np.float64(v)
+        print(tag, "reference t1 vs t8:", {k: f"{v:.3e}" for k, v in spread.items()}, "layer_loss", a["layer_loss"],
+              b["layer_loss"], "best it", int(np.argmin(a["loss_hist"])), int(np.argmin(b["loss_hist"])))
+        # the oracle: fp32 mode == reference (8 threads), fp64 mode = anchor
+        pyr = [torch.ones(1, S // 2, S // 2, S // 2), inp["mask"]]
+        chk = O.calibrate_layer(inp["x"], inp["y"], inp["w"], inp["b"], 1, 1, qlvl_w=4, qlvl_act=4, mask_pyramid=pyr)
+        d_or = abs(chk.layer_loss - b["layer_loss"]) / b["layer_loss"]
+        idx_or = (lv(chk.weight) != lv(b["weight"])).float().mean().item()
+        print(tag, "oracle fp32 vs reference t8: layer_loss rel", d_or, "idx mismatch", idx_or,
+              "loss hist equal:", np.array_equal(np.array(chk.loss_history), b["loss_hist"]))
+        out[f"{tag}_oracle32_layer_loss"] = np.float64(chk.layer_loss)
+        r = O.calibrate_layer(inp["x"], inp["y"], inp["w"], inp["b"], 1, 1, qlvl_w=4, qlvl_act=4, mask_pyramid=pyr,
+                              dtype=torch.float64)
+        out[f"{tag}_f64_loss_hist"] = np.array(r.loss_history, dtype=np.float64)
+        out[f"{tag}_f64_wstar0"] = r.wstar0.float()
+        out[f"{tag}_f64_bstar0"] = r.bstar0
+        out[f"{tag}_f64_weight_idx"] = lv(r.weight.float()).to(torch.uint8)
+        out[f"{tag}_f64_layer_loss"] = np.float64(r.layer_loss)
+        out[f"{tag}_f64_alpha_act"] = np.float64(r.alpha_act)
+        for nt in (1, 8):
+            print(tag, f"t{nt} vs fp64: layer_loss rel", abs(recs[nt]["layer_loss"] - r.layer_loss) / r.layer_loss,
+                  "idx mismatch", (lv(recs[nt]["weight"]) != lv(r.weight.float())).float().mean().item(),
+                  "w*0 rel", ((recs[nt]["wstar0"].double() - r.wstar0.double()).norm() / r.wstar0.double().norm()).item())
+    save("g5e_wide_layer_many_voxels.npz", **out)
+
+
 # ---------------------------------------------------------------- G6 whole do_ptq
+def _shape3(S):
+    return tuple(S) if isinstance(S, (tuple, list)) else (S, S, S)
+
+
 def tiny_args(task, L, S, nmod, ncls, multi_label=None, init_stride="1", width="8,16,8",
               depth="1,1,1", root="/tmp/effq_gold"):
     return argparse.Namespace(
@@ -384,7 +473,7 @@ def tiny_args(task, L, S, nmod, ncls, multi_label=None, init_stride="1", width="
         width=width, depth=depth, dilation=None, nla="relu", norm="bn", drop_rate=0.5, ds="simple",
         init_kernel=3, hetero_dim=True, blk="mid", qconv="effq", qlvl_w=L, qlvl_a=L,
         q_first="256,-1", q_last="256,-1", lwq_dataid=0, lwq_batchsz=2,
-        lwq_patchsz=f"{S},{S},{S}", lwq_verbose=False)
+        lwq_patchsz=",".join(str(v) for v in _shape3(S)), lwq_verbose=False)
 
 
 def randomise(model, seed):
@@ -411,9 +500,10 @@ def _copying_hook(m, i, o):
     m.output_fp = o.detach().clone()
 
 
-def run_do_ptq(task, L, S, width="8,16,8", copy_targets=False, threads=8, seed=606):
+def run_do_ptq(task, L, S, width="8,16,8", copy_targets=False, threads=8, seed=606, lits_stride="1"):
     """The reference's real do_ptq (ptqer.py:282-387) on a seeded random network and seeded volumes; returns what it
-    produced.  copy_targets: hooks.py:5-6 as it behaves on a GPU (see _copying_hook)."""
+    produced.  copy_targets: hooks.py:5-6 as it behaves on a GPU (see _copying_hook).  lits_stride: init_stride of the
+    LiTS-style net ("2,2,1" = config/lits_ptq.yaml: anisotropic first conv, mask pyramid and final up-sampling)."""
     root = "/tmp/effq_gold"
     torch.set_num_threads(threads)
     orig_hook = ptqer.forward_hook
@@ -421,7 +511,7 @@ def run_do_ptq(task, L, S, width="8,16,8", copy_targets=False, threads=8, seed=6
         ptqer.forward_hook = _copying_hook
     os.makedirs(root + "/snap", exist_ok=True)
     if task == "lits":
-        args = tiny_args("lits", L, S, 1, 3, width=width)
+        args = tiny_args("lits", L, S, 1, 3, width=width, init_stride=lits_stride)
     else:
         args = tiny_args("brats", L, S, 2, 4, multi_label="brats", init_stride="2,2,2", width=width)
     QConv, Qinfo, kwQ = definer.get_conv_class(args)
@@ -432,7 +522,7 @@ def run_do_ptq(task, L, S, width="8,16,8", copy_targets=False, threads=8, seed=6
     torch.save({"state_dict": model.state_dict()}, args.pretrain)
     nmod = args.nMod
     g = torch.Generator().manual_seed(1)
-    vols = torch.randn(2, nmod, S, S, S, generator=g)
+    vols = torch.randn(2, nmod, *_shape3(S), generator=g)
     if task == "brats":
         zz = torch.arange(S).float() - (S - 1) / 2
         r = (zz[:, None, None] ** 2 + zz[None, :, None] ** 2 + zz[None, None, :] ** 2).sqrt()
@@ -443,7 +533,7 @@ def run_do_ptq(task, L, S, width="8,16,8", copy_targets=False, threads=8, seed=6
             return 2
 
         def __getitem__(s, i):
-            return vols[i], torch.zeros(S, S, S).long()
+            return vols[i], torch.zeros(*_shape3(S)).long()
 
         def use_fix_transform(s):
             pass
@@ -486,8 +576,8 @@ def run_do_ptq(task, L, S, width="8,16,8", copy_targets=False, threads=8, seed=6
     return dict(ll=ll, nums=nums, outs=outs, captured=captured, sd0=sd0, vols=vols, L=L, S=S)
 
 
-def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_targets=False):
-    r = run_do_ptq(task, L, S, copy_targets=copy_targets)
+def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_targets=False, lits_stride="1"):
+    r = run_do_ptq(task, L, S, copy_targets=copy_targets, lits_stride=lits_stride)
     ll, nums, outs, captured, sd0, vols = r["ll"], r["nums"], r["outs"], r["captured"], r["sd0"], r["vols"]
     sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4), slice(None, None, 4))
     out = {"vols_seed": np.int64(1), "vols_check": vols[:, :, ::8, ::8, ::8],
@@ -498,7 +588,7 @@ def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_tar
            "layer_names": np.array([l.split(":")[0].strip() for l in ll]),
            "layer_loss": np.array([float(l.split(":")[1]) for l in ll], dtype=np.float64),
            "class_nums": np.array(nums, dtype=np.int64),
-           "meta": np.array([L, S])}
+           "meta": np.array([L, _shape3(S)[0]]), "shape": np.array(_shape3(S)), "init_stride": np.array(lits_stride if task == "lits" else "2,2,2")}
     for i, p in enumerate(captured["pyr"]):
         out[f"pyr{i}"] = p.to(torch.uint8)
         assert (p == p.to(torch.uint8).float()).all()
@@ -597,14 +687,16 @@ def g8():
         data[:, :, :, :, 6:] = 0
         body = (data[:, 0] != 0).bool() if task == "brats" else torch.ones_like(data[:, 0]).bool()
         wmap, nums = ptqer.get_att_weight_map(logits, torch.ones_like(data[:, 0]).bool(), "p:0.5", task=task)
-        for st in ("1", "2,2,2"):
+        for st in ("1", "2,2,2", "2,2,1"):
             if st != "1":
-                lg = F.interpolate(logits[-1], scale_factor=2, mode="trilinear")[None]
-                dt = F.interpolate(data, scale_factor=2, mode="nearest")
+                # ("2,2,1" = config/lits_ptq.yaml: avg_pool3d(out, (2,2,1)) as the pyramid's first level, ptqer.py:148-150)
+                sf = tuple(float(v) for v in st.split(","))
+                lg = F.interpolate(logits[-1], scale_factor=sf, mode="trilinear")[None]
+                dt = F.interpolate(data, scale_factor=sf, mode="nearest")
                 bd = (dt[:, 0] != 0).bool() if task == "brats" else torch.ones_like(dt[:, 0]).bool()
                 wm, nm = ptqer.get_att_weight_map(lg, torch.ones_like(dt[:, 0]).bool(), "p:0.5", task=task)
                 pyr = ptqer.get_mask_pyramid(lg, bd, wm, st, num_lvls=3, task=task)
-                key = f"{task}_s2"
+                key = f"{task}_s2" if st == "2,2,2" else f"{task}_s221"
                 out[f"{key}_logits"], out[f"{key}_data"] = lg, dt
             else:
                 wm, nm = wmap, nums
@@ -725,7 +817,8 @@ def g12():
 
 
 if __name__ == "__main__":
-    ALL = ["g1", "g2", "g3g4", "g5", "g5b", "g5d", "g6", "g6b", "g6c", "g6d", "g7", "g8", "g9", "g10", "g11", "g12"]
+    ALL = ["g1", "g2", "g3g4", "g5", "g5b", "g5d", "g5e", "g6", "g6b", "g6c", "g6d", "g6e", "g6f", "g7", "g8", "g9", "g10",
+           "g11", "g12"]
     which = sys.argv[1:] or ALL
     with torch.no_grad():
         for name, fn in (("g1", g1), ("g2", g2), ("g3g4", g3_g4), ("g7", g7), ("g8", g8), ("g9", g9), ("g10", g10),
@@ -745,6 +838,16 @@ if __name__ == "__main__":
     if "g6c" in which:
         g6("lits", 4, 32, "g6c_tiny_lits_L4", copy_targets=True)
         g6("brats", 4, 64, "g6c_tiny_brats_L4", copy_targets=True)
+    if "g5e" in which:
+        g5e()
+    if "g6e" in which:
+        # LiTS geometry: init_stride "2,2,1" through the real do_ptq, GPU hook behaviour
+        # (the pyramid pools five more times after the initial stride, ptqer.py:154-167: the strided axes need 64 voxels)
+        g6("lits", 4, (64, 64, 32), "g6e_tiny_lits_s221_L4", copy_targets=True, lits_stride="2,2,1")
+    if "g6f" in which:
+        # configs[2] arithmetic on a whole net: 16 / 16 levels, GPU hook behaviour
+        g6("lits", 16, 32, "g6f_tiny_lits_L16", copy_targets=True)
+        g6("brats", 16, 64, "g6f_tiny_brats_L16", copy_targets=True)
     if "g6d" in which:
         g6d()
     if "g6d_lits" in which:
