@@ -304,8 +304,14 @@ int effq_admm_run(const effq_admm_run_args* a) {
   // to be ready after, and the chain waited for each of the three later ones in turn (LiTS: 3.08 -> 3.03 s per calibration;
   // BraTS 900 -> 893 ms).  EFFQ_SIDE_EARLY_N = smallest n that does so (tuning aid).
   static const int early_n = getenv("EFFQ_SIDE_EARLY_N") ? atoi(getenv("EFFQ_SIDE_EARLY_N")) : 0;
+  // ... unless the later inverses are quick enough to be ready in time when they start AFTER the first one (n below
+  // EFFQ_SIDE_SERIAL_BELOW): beside two other sweeps the first inverse - which the whole chain waits for - took 2 x as
+  // long as alone (n = 3457: 7.3 against 3.6 ms, 1729: 3.1 against 1.5), and the later ones then run one after the other
+  // on ONE side stream, the one that is needed next always first.
+  static const int serial_below = getenv("EFFQ_SIDE_SERIAL_BELOW") ? atoi(getenv("EFFQ_SIDE_SERIAL_BELOW")) : 0;
+  const bool side_serial = fork_side && n_inv > 1 && n < serial_below;
   const bool side_early = fork_side && n_inv > 1 && n >= early_n;
-  if (side_early) {
+  if (side_early && !side_serial) {
     ADMM_HIP(new_event(&ev_fork));
     ADMM_HIP(hipEventRecord(ev_fork, s_main));         // A0 (and everything before the call) is ready
     ADMM_HIP(hipStreamWaitEvent(s_side, ev_fork, 0));
@@ -316,6 +322,11 @@ int effq_admm_run(const effq_admm_run_args* a) {
     ADMM_RC(effq_spd_inverse(a->A0, n, has_b, plan.rho[first], a->eta, a->ainv_pool, a->inv_ws, a->inv_ws_bytes, s_main));
     ps.close();
   }
+  if (side_serial) {
+    ADMM_HIP(new_event(&ev_fork));
+    ADMM_HIP(hipEventRecord(ev_fork, s_main));         // the first inverse has finished
+    ADMM_HIP(hipStreamWaitEvent(s_side, ev_fork, 0));
+  }
   // The later inverses (side stream) are ENQUEUED a few iterations into the loop, not here: their ~30 - 650 launches take
   // the host 0.2 - 2.6 ms, during which the main stream - done with its own inverse on the small layers - had nothing queued
   // (under a profiler, at 3 x the launch cost, 6 ms per layer).  The side stream still starts from the fork event recorded
@@ -323,7 +334,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
   bool side_enqueued = (n_inv <= 1);
   auto enqueue_side_inverses = [&]() -> int {
     side_enqueued = true;
-    if (fork_side && !side_early) {
+    if (fork_side && !side_early && !side_serial) {
       hipError_t e1 = new_event(&ev_fork);
       if (e1 == hipSuccess) e1 = hipEventRecord(ev_fork, s_main);       // A0 (and everything before the call) is ready
       if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s_side, ev_fork, 0);
@@ -335,7 +346,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
     }
     for (int r = first + 1; r < plan.count; ++r) {
       float* dst = a->ainv_pool + (size_t)(r - first) * ainv_elems;
-      const bool on2 = two_sides && ((r - first) % 2 == 0);       // first later inverse on side 1, the next on side 2 ...
+      const bool on2 = two_sides && !side_serial && ((r - first) % 2 == 0);   // first later inverse on side 1, the next on side 2 ...
       hipStream_t sr = on2 ? s_side2 : s_side;
       void* ws = !fork_side ? a->inv_ws : (on2 ? a->inv_ws_side2 : a->inv_ws_side);
       const size_t wsb = !fork_side ? a->inv_ws_bytes : (on2 ? a->inv_ws_side2_bytes : a->inv_ws_side_bytes);

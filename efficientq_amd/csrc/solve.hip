@@ -569,6 +569,122 @@ __global__ __launch_bounds__(256) void k_gj_wback_w(double* __restrict__ A, int 
   }
 }
 
+// The next pivot block of the 128-row sweep in ONE launch of ONE workgroup (16 waves): the 128 x 128 block is held in
+// LDS (133 KB), the pending rank-kdim update of its own tile applied while it is loaded (operands straight from the
+// K-major panels), then inverted by blocks: D0 = inv(M00), Z = M10 D0, S = M11 - Z M01, inv(S), W = inv(S) Z,
+//   inverse = [[D0 + Z^T W, -W^T], [-W, inv(S)]],
+// the two 64 x 64 inversions in registers (gj_invert_regs, 16 waves), the four 64^3 products on the matrix cores (one
+// 16 x 16 tile per wave).  Replaces a chain of ~8 launches per pivot block (tile update, diag, panel, trailing, mirror).
+constexpr int PF_LD = 130;      // LDS pitch (doubles): operand fetches indexed [row = lane & 15][k = lane >> 4] are conflict-free
+__device__ __forceinline__ f64x4 mm16(f64x4 acc, const double* Aop, int a_rs, int a_cs, const double* Bop, int b_rs,
+                                      int b_cs, int K, int lr, int lk) {
+#pragma unroll 4
+  for (int ks = 0; ks < K / 4; ++ks) {
+    const double a = Aop[lr * a_rs + (ks * 4 + lk) * a_cs];
+    const double b = Bop[(ks * 4 + lk) * b_rs + lr * b_cs];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(1024) void k_gj_pivot_fused(const double* __restrict__ A, int npad, int k0, int mk,
+                                                         const double* __restrict__ NZT, const double* __restrict__ XTW,
+                                                         size_t ldx, int kdim, double* __restrict__ Dw) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* M = sm;                                                        // [128][PF_LD]
+  double(*fcol)[NBK + 1] = reinterpret_cast<double(*)[NBK + 1]>(sm + 2 * NBK * PF_LD);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tr = wid >> 2, tc = wid & 3;
+  const int lr = lane & 15, lk = lane >> 4;
+  // ---- the block with the pending update applied: upper 64-blocks computed, the lower one mirrored
+  for (int bi = 0; bi < mk; ++bi)
+    for (int bj = bi; bj < mk; ++bj) {
+      const size_t row0 = (size_t)(k0 + bi) * NBK + tr * 16, col0 = (size_t)(k0 + bj) * NBK + tc * 16;
+      f64x4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = A[(row0 + lk + 4 * r) * npad + col0 + lr];
+      const double* Ag = NZT + row0 + lr;
+      const double* Bg = XTW + col0 + lr;
+#pragma unroll 8
+      for (int ks = 0; ks < kdim / 4; ++ks) {
+        const double a = Ag[(size_t)(ks * 4 + lk) * ldx];
+        const double b = Bg[(size_t)(ks * 4 + lk) * ldx];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = bi * NBK + tr * 16 + lk + 4 * r, cc = bj * NBK + tc * 16 + lr;
+        M[rr * PF_LD + cc] = acc[r];
+        if (bi < bj) M[cc * PF_LD + rr] = acc[r];
+      }
+    }
+  lds_barrier();
+  constexpr int CPW = NBK / 16;                                          // 16 waves, 4 columns each, lane = row
+  auto invert64 = [&](int off) {
+    double reg[CPW];
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) reg[j] = M[(off + lane) * PF_LD + off + wid * CPW + j];
+    gj_invert_regs<CPW>(reg, fcol, lane, wid);
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) M[(off + lane) * PF_LD + off + wid * CPW + j] = reg[j];
+    lds_barrier();
+  };
+  auto zero = []() {
+    f64x4 z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = 0.0;
+    return z;
+  };
+  auto tile_store = [&](int rb, int cb, f64x4 v, double sgn) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) M[(rb + tr * 16 + lk + 4 * r) * PF_LD + cb + tc * 16 + lr] = sgn * v[r];
+  };
+  auto tile_load = [&](int rb, int cb) {
+    f64x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = M[(rb + tr * 16 + lk + 4 * r) * PF_LD + cb + tc * 16 + lr];
+    return v;
+  };
+  invert64(0);                                                            // M00 <- D0
+  if (mk == 2) {
+    // Z = M10 D0 (into the M10 region, once every wave has read its operands)
+    f64x4 z = mm16(zero(), M + (NBK + tr * 16) * PF_LD, PF_LD, 1, M + tc * 16, PF_LD, 1, NBK, lr, lk);
+    lds_barrier();
+    tile_store(NBK, 0, z, 1.0);
+    lds_barrier();
+    // S = M11 - Z M01, in place
+    f64x4 sacc = tile_load(NBK, NBK);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sacc[r] = -sacc[r];
+    sacc = mm16(sacc, M + (NBK + tr * 16) * PF_LD, PF_LD, 1, M + NBK + tc * 16, PF_LD, 1, NBK, lr, lk);
+    tile_store(NBK, NBK, sacc, -1.0);
+    lds_barrier();
+    invert64(NBK);                                                        // M11 <- inv(S)
+    // W = inv(S) Z -> the M01 region (M01 itself is no longer needed)
+    f64x4 w = mm16(zero(), M + (NBK + tr * 16) * PF_LD + NBK, PF_LD, 1, M + NBK * PF_LD + tc * 16, PF_LD, 1, NBK, lr, lk);
+    tile_store(0, NBK, w, 1.0);
+    lds_barrier();
+    // M00 <- D0 + Z^T W   (A operand (m, k) = Z[k][m])
+    f64x4 d = tile_load(0, 0);
+    d = mm16(d, M + NBK * PF_LD + tr * 16, 1, PF_LD, M + NBK + tc * 16, PF_LD, 1, NBK, lr, lk);
+    tile_store(0, 0, d, 1.0);
+    lds_barrier();
+  }
+  // ---- out: [[M00, -W^T], [-W, M11]] with W in the M01 region
+  const int nd = mk * NBK;
+  for (int e = tid; e < nd * nd; e += 1024) {
+    const int i = e / nd, j = e % nd;
+    double v;
+    if (i < NBK && j >= NBK)
+      v = -M[(j - NBK) * PF_LD + NBK + i];
+    else if (i >= NBK && j < NBK)
+      v = -M[(i - NBK) * PF_LD + NBK + j];
+    else
+      v = M[i * PF_LD + j];
+    Dw[e] = v;
+  }
+}
+
 // the rank-64 sweep keeps the upper 64-block triangle: fill in the blocks below the diagonal (the finished inverse is
 // symmetric)
 __global__ __launch_bounds__(256) void k_mirror_blocks(double* __restrict__ D, int nd) {
@@ -1043,7 +1159,10 @@ static size_t gj64_aux_doubles(size_t npad) { return 2 * (size_t)NBK * npad + 2 
 // the wide sweep (pivot blocks of 256) from this many 64-blocks on; EFFQ_GJ_WIDE=0: the rank-64 sweep everywhere (A/B)
 static int gj_wide_min_blocks() {
   static const int off = getenv("EFFQ_GJ_WIDE") != nullptr && atoi(getenv("EFFQ_GJ_WIDE")) == 0;
-  static const int mn = getenv("EFFQ_GJ_WIDE_MIN") ? atoi(getenv("EFFQ_GJ_WIDE_MIN")) : 2 * WB;
+  // measured inside the calibration (ms per calibration, one box): rank-64 sweep everywhere 689.6; 256-row pivot blocks
+  // from n = 6400 on 671.0; 256-row (or 128-row, fused pivot launch) blocks for every n >= 512: 683.5 / 681.8 - below
+  // n ~ 5000 an inverse is a chain of dependent launches either way, and the rank-64 sweep has the shortest one
+  static const int mn = getenv("EFFQ_GJ_WIDE_MIN") ? atoi(getenv("EFFQ_GJ_WIDE_MIN")) : 100;
   return off ? (1 << 30) : mn;
 }
 
@@ -1115,6 +1234,10 @@ static int gj_wide_ctx(hipStream_t caller, GjWideCtx** out) {
 
 static int gj_wide_sweep(double* A64, int npad, double* aux, hipStream_t st) {
   const int nblk = npad / NBK;
+  // pivot blocks of 128 rows (next pivot block by ONE fused launch) below EFFQ_GJ_WB4_MIN 64-blocks, of 256 rows from there
+  // on (the triangle no longer fits the Infinity Cache: the rank-256 update halves the bytes per flop once more)
+  static const int wb4_min = getenv("EFFQ_GJ_WB4_MIN") ? atoi(getenv("EFFQ_GJ_WB4_MIN")) : 100;
+  const int WB = (nblk >= wb4_min) ? effq::WB : 2;
   const size_t ldx = (size_t)round_up(npad, BG_T);
   double* NZT = aux;                               // [256][ldx]
   double* XTW = NZT + (size_t)WK * ldx;            // [256][ldx]
@@ -1129,6 +1252,7 @@ static int gj_wide_sweep(double* A64, int npad, double* aux, hipStream_t st) {
   }
   hipStream_t s2 = ctx ? ctx->helper : st;
   const size_t lds = (size_t)(NBK * LDA_S + NBK * LDB_S) * sizeof(double);
+  const size_t pf_lds = (size_t)(2 * NBK * PF_LD + 2 * (NBK + 1)) * sizeof(double);
   auto pivot_block = [&](int k0, int mk, int kdim, hipStream_t s) -> int {
     // Dw = the pivot block (blocks k0 .. k0 + mk - 1) with the pending rank-kdim update applied, then inverted
     GjBig g;
@@ -1138,6 +1262,11 @@ static int gj_wide_sweep(double* A64, int npad, double* aux, hipStream_t st) {
     g.NZT = NZT; g.XTW = XTW; g.ldx = ldx; g.kdim = kdim; g.nblk = nblk;
     g.i0m = k0 / 2; g.j0m = k0 / 2;
     g.skip_lo = g.skip_hi = -1; g.la_lo = g.la_hi = -1;
+    if (WB == 2) {
+      hipLaunchKernelGGL(k_gj_pivot_fused, dim3(1), dim3(1024), pf_lds, s, A64, npad, k0, mk, NZT, XTW, ldx, kdim, Dw);
+      EFFQ_LAUNCH_CHECK();
+      return EFFQ_OK;
+    }
     const int span = (mk + 1) / 2;
     hipLaunchKernelGGL(k_gj_big, dim3(span, span), dim3(256), 0, s, g);
     EFFQ_LAUNCH_CHECK();
@@ -1160,6 +1289,8 @@ static int gj_wide_sweep(double* A64, int npad, double* aux, hipStream_t st) {
       EFFQ_HIP(hipEventRecord(ctx->e1, st));
       EFFQ_HIP(hipStreamWaitEvent(s2, ctx->e1, 0));
     }
+    // (the write-back reads the inverse of THIS pivot block from Dw: before the next pivot block overwrites it.  It is
+    // a copy of n x 64 m doubles; the pivot work behind it on the helper stream is the part that must not wait)
     hipLaunchKernelGGL(k_gj_wback_w, dim3(nblk, m), dim3(256), 0, s2, A64, npad, kb0, m, Dw, NZT, ldx);
     EFFQ_LAUNCH_CHECK();
     if (mn > 0) {
@@ -1209,6 +1340,8 @@ int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double et
   if (!attr_set) {
     EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_panel_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_pivot_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)((2 * NBK * PF_LD + 2 * (NBK + 1)) * sizeof(double))));
     attr_set = true;
   }
   const int rc = (npad / NBK >= gj_wide_min_blocks()) ? gj_wide_sweep(A64, npad, aux, st) : gj64_sweep(A64, npad, aux, st);

@@ -418,7 +418,6 @@ def g5e():
             assert torch.equal(rec["x"], inp["x"]) and torch.equal(rec["y"], inp["y"])
             fq = rec["fwd_q"]
             out[f"{tag}_t{nt}_fwd_q_sub"] = fq[:, :, ::sub, ::sub, ::sub].contiguous()
-            out[f"{tag}_t{nt}_fwd_q_chk"] = GI.checksums(fq)
             for k in ("loss_hist", "final_mse", "aw_hist", "weight", "bias", "alpha_w", "alpha_act", "layer_loss",
                       "wstar0", "bstar0", "G0idx"):
                 out[f"{tag}_t{nt}_{k}"] = rec[k]

@@ -17,22 +17,35 @@ G5E_CASES = {
 }
 
 
+def gauss_int(gen, *shape):
+    """Near-normal variates (sum of four uniform integers, unit variance to 0.03 %) built from torch.randint and exact
+    fp32 arithmetic only.  torch.randn is NOT bit-reproducible between hosts (its vectorised log / cos differ in the last
+    bit on a few elements between CPU generations: the first version of this fixture failed its checksums on the GPU
+    box's host for exactly that reason); the integer generator and IEEE + - * / are."""
+    k = torch.zeros(shape, dtype=torch.int64)
+    for _ in range(4):
+        k += torch.randint(-1024, 1025, shape, generator=gen)
+    return k.float() / 1183.5          # |k| <= 4096: exact in fp32; one correctly rounded division
+
+
 def wide_layer_inputs(S, seed, c1=32, c2=32):
     """-> dict(w, b, x_fp, x, y, mask): start weights, FP input, quantised-upstream stand-in (quirk Q9), exact FP target,
     integer-valued attention mask (quirk Q1) of one 3^3 layer on a 1 x c1 x S^3 volume."""
     gen = torch.Generator().manual_seed(seed)
     sigma = 1.0 / (c1 * 27) ** 0.5
-    w = torch.round(torch.randn(c2, c1, 3, 3, 3, generator=gen) * sigma * 1024).clamp_(-255, 255) / 1024
-    b = torch.round(torch.randn(c2, generator=gen) * 0.1 * 16384) / 16384
-    x_fp = torch.round(torch.relu(torch.randn(1, c1, S, S, S, generator=gen)) * 16).clamp_(max=127) / 16
-    x = torch.relu(x_fp + 0.05 * torch.randn(x_fp.shape, generator=gen))
+    w = torch.round(gauss_int(gen, c2, c1, 3, 3, 3) * sigma * 1024).clamp_(-255, 255) / 1024
+    b = torch.round(gauss_int(gen, c2) * 0.1 * 16384) / 16384
+    x_fp = torch.round(torch.relu(gauss_int(gen, 1, c1, S, S, S)) * 16).clamp_(max=127) / 16
+    x = torch.relu(x_fp + 0.05 * gauss_int(gen, *x_fp.shape))
     mask = torch.randint(1, 4, (1, S, S, S), generator=gen).float()
     y = F.conv3d(x_fp, w, b, 1, 1)
     return dict(w=w, b=b, x_fp=x_fp, x=x, y=y, mask=mask)
 
 
 def checksums(t):
-    """(sum, sum of squares, weighted sum) in fp64: equal only for equal tensors, for all practical purposes."""
-    d = t.double().flatten()
-    ramp = torch.arange(d.numel(), dtype=torch.float64) % 1009
-    return torch.stack([d.sum(), (d * d).sum(), (d * ramp).sum()])
+    """Order-independent checksums of an fp32 tensor: the int64 sum of its bit patterns, and the same weighted by a ramp.
+    (fp64 sums of the VALUES depend on the summation order, which differs between hosts with different vector widths:
+    the first version of this function failed on the GPU box's host for equal tensors.)"""
+    bits = t.contiguous().view(torch.int32).flatten().to(torch.int64)
+    ramp = torch.arange(bits.numel(), dtype=torch.int64) % 1009
+    return torch.stack([bits.sum(), (bits * ramp).sum()])

@@ -1,8 +1,7 @@
 """BASELINE.json's configurations at their real network geometry (-m gpu): the BraTS net of config 2 / 3 at 4/4 and 16/16
 levels on full 4x128^3 volumes, the LiTS net of config 4 on 1x160^3 volumes (widths to 512, n = 13825), the tiny net of
 config 1 at 256/256 levels - each through calibrate_model - and the solver at the system sizes those networks reach
-(n = 6913, 13825).  Volumes per GPU are cut to 2 to keep the suite short; everything per-layer (shapes, system sizes,
-kernels chosen) is what the full configurations run."""
+(n = 6913, 13825).  configs[1..4] run at the per-GPU shard BASELINE.json states (16 / 8 / 8 volumes, 4 for the sweep)."""
 import numpy as np
 import pytest
 import torch
@@ -116,35 +115,78 @@ def test_fp_targets_are_snapshots_taken_before_the_in_place_relu():
     assert len(negative) == len(layers), set(n for n, _ in layers) - set(negative)     # no target is a ReLU output
 
 
-def test_config3_brats_net_16_levels():
-    """configs[2] arithmetic (16/16 levels: 176-iteration activation fixed points, 57-iteration weight fixed points,
-    16-level exact-integer convs and Gram systems) on the BraTS net."""
-    from efficientq_amd import calibrate as K, config as Cf, synth
-    args, model = _build(Cf.BRATS_NET, 16)
-    vols = synth.calib_batch("brats", range(2), 128)
+def _stated_size_run(net, L, task, n_layers, vols, agree_floor):
+    """Two calibrations of the same pristine network on the shard a GPU holds in the configuration: structure checks and
+    bit-for-bit determinism (what keeps data-parallel replicas in lock step)."""
+    from efficientq_amd import calibrate as K
+    args, model = _build(net, L)
+    pristine = {k: v.clone() for k, v in model.state_dict().items()}
     model.to(DEV)
-    res = K.calibrate_model(model, vols.to(DEV), "brats", args.init_stride)
-    _, agree = _check_calibrated(model, res, 22, "brats", 0.95)
-    used_int = [m.last_trace["exact_int"] for _, m in _qlayers(model)]
-    # the layers with quantised input run their losses on the i8 matrix cores: all but the first conv, the classifier
-    # (FP input) and the 256 -> 128 1^3 conv (too many B operands for the short-K kernel: fp32 path)
+    runs = []
+    for _ in range(2):
+        model.load_state_dict({k: v.to(DEV) for k, v in pristine.items()}, strict=True)
+        res = K.calibrate_model(model, vols, task, args.init_stride)
+        losses, agree = _check_calibrated(model, res, n_layers, task, agree_floor)
+        runs.append((losses, agree, {k: v.clone() for k, v in model.state_dict().items()}, res["output_q"][-1].clone(),
+                     res["t2"] - res["t0"]))
+    assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
+    assert torch.equal(runs[0][3], runs[1][3])
+    return model, runs[0]
+
+
+def test_config3_brats_net_16_levels_at_its_stated_size():
+    """configs[2] as BASELINE.json states it for ONE of its 8 GPUs: 8 volumes of 4x128^3, 16/16 levels (176-iteration
+    activation fixed points, 57-iteration weight fixed points, 16-level exact-integer convs and Gram systems)."""
+    from efficientq_amd import config as Cf, synth
+    vols = synth.calib_batch("brats", range(8), 128).to(DEV)
+    model, (losses, agree, _, _, secs) = _stated_size_run(Cf.BRATS_NET, 16, "brats", 22, vols, 0.985)
+    # the layers with quantised input run their losses on the i8 matrix cores / from the integer Gram system: all but the
+    # 256 -> 128 1^3 conv (too many B operands for the short-K kernel: fp32 path) and, at most, the two FP-input layers
     f32 = [n for n, m in _qlayers(model) if not m.last_trace["exact_int"]]
     assert len(f32) <= 4, f32
-    print(f"config 3 arithmetic: FP-vs-Q agreement {agree:.4f}")
+    for name, m in _qlayers(model)[1:-1]:
+        assert torch.unique(m.weight.data).numel() > 4, name          # 16 levels are in use, not 4
+    print(f"config 3 at 8 volumes per GPU: FP-vs-Q agreement {agree:.4f}, sum layer_loss {losses.sum():.4f}, {secs:.2f} s")
 
 
-def test_config4_lits_net_widths_to_512():
-    """configs[3] geometry: the LiTS net (28 quantised convs, widths 32..512, init_stride 2,2,1) on 1x160^3 volumes:
-    n = 13825 Gram systems / inverses and 7.08 M-weight projections."""
-    from efficientq_amd import calibrate as K, config as Cf, synth
-    args, model = _build(Cf.LITS_NET, 4)
-    vols = synth.calib_batch("lits", range(2), 160)
-    model.to(DEV)
-    res = K.calibrate_model(model, vols.to(DEV), "lits", args.init_stride)
-    _, agree = _check_calibrated(model, res, 28, "lits", 0.80)
-    widest = max(m.in_channels for _, m in _qlayers(model))
-    assert widest == 512
-    print(f"config 4 geometry: FP-vs-Q agreement {agree:.4f}")
+def test_config4_lits_net_at_its_stated_size():
+    """configs[3] as BASELINE.json states it for ONE of its 4 GPUs: 8 volumes of 1x160^3 through the LiTS net (28 quantised
+    convs, widths 32..512, init_stride 2,2,1: n = 13825 Gram systems / inverses, 7.08 M-weight projections)."""
+    from efficientq_amd import config as Cf, synth
+    vols = synth.calib_batch("lits", range(8), 160).to(DEV)
+    model, (losses, agree, _, out_q, secs) = _stated_size_run(Cf.LITS_NET, 4, "lits", 28, vols, 0.80)
+    assert max(m.in_channels for _, m in _qlayers(model)) == 512
+    assert tuple(out_q.shape) == (8, 3, 160, 160, 160)               # final up-sampling x (2, 2, 1) back to the input grid
+    print(f"config 4 at 8 volumes per GPU: FP-vs-Q agreement {agree:.4f}, sum layer_loss {losses.sum():.4f}, {secs:.2f} s")
+
+
+def test_config5_mixed_precision_search_on_full_size_volumes():
+    """configs[4]: per-layer qlvl_w in {4, 8, 16} over the BraTS net on 4 volumes of 4x128^3 (one GPU of the 8: budgets are
+    independent replicas), activation levels following the weight levels.  ADVICE r3: an assertion with power - at this
+    size the searched 2.5-bit map must beat uniform 2 bits by a factor far outside the 8 % build-to-build spread of one
+    map's end-to-end error (r3 sweep: 0.0017 against 0.0101), and reach the uniform 4-bit network within 1.5 x."""
+    from efficientq_amd import calibrate as K, config as Cf, mixed, synth
+    args = Cf.make_args(Cf.BRATS_NET, 4, 4)
+    QConv, _, kwQ = Cf.get_conv_class(args)
+
+    def build():
+        m = Cf.get_model_cube(args, QConv, kwQ)[0]["model"]
+        synth.randomise_network(m, 0)
+        m.eval(); K.search_fold_and_remove_bn(m); m.to(DEV); K.set_name(m)
+        return m
+    vols = synth.calib_batch("brats", range(4), 128).to(DEV)
+    res = mixed.search(build, vols, "brats", args.init_stride, [2.0, 2.5, 3.0], levels=(4, 8, 16), act_follows=True)
+    u16 = mixed.uniform(build, vols, "brats", args.init_stride, 16, act_follows=True)
+    e = [r["output_error"] for r in res]
+    print("config 5:", [(r["budget_bits"], round(r["avg_bits"], 3), r["output_error"], r["agreement"]) for r in res], u16)
+    for r, b in zip(res, (2.0, 2.5, 3.0)):
+        assert r["avg_bits"] <= b + 1e-9 and set(r["levels"].values()) <= {4, 8, 16} and len(r["levels"]) == 20
+    assert set(res[0]["levels"].values()) == {4}
+    assert e[1] <= 0.5 * e[0] and e[2] <= 0.5 * e[0], e                 # the search buys a factor, not a few percent
+    assert e[1] <= 1.5 * u16["output_error"], (e, u16["output_error"])
+    assert res[1]["agreement"] >= res[0]["agreement"]
 
 
 def test_config1_tiny_net_256_levels():

@@ -41,9 +41,11 @@ def test_product_path_refuses_cpu_tensors():
 
 
 # ------------------------------------------------------------------ graph / state_dict / BN fold / masks
-def _tiny(task, L=4, width=None):
+def _tiny(task, L=4, width=None, init_stride=None):
     from efficientq_amd import config as Cf
     base = dict(Cf.TINY_NET, width=width) if width else Cf.TINY_NET
+    if init_stride:
+        base = dict(base, init_stride=init_stride)
     if task == "lits":
         args = Cf.make_args(base, L, L, lwq_batchsz=2)
     else:
@@ -109,7 +111,7 @@ def test_resunit_inplace_relu_residual(gold):
 def test_attention_masks_match_reference(gold, task):
     from efficientq_amd import calibrate as K
     g = gold("g8_attmask.npz")
-    for key, st in ((f"{task}_s1", "1"), (f"{task}_s2", "2,2,2")):
+    for key, st in ((f"{task}_s1", "1"), (f"{task}_s2", "2,2,2"), (f"{task}_s221", "2,2,1")):
         logits, data = T(g[f"{key}_logits"]), T(g[f"{key}_data"])
         ones = torch.ones_like(data[:, 0]).bool()
         body = (data[:, 0] != 0).bool() if task == "brats" else ones
@@ -242,6 +244,40 @@ def test_whole_calibration_on_oracle_backend_matches_reference(gold, monkeypatch
     for k in g.files:
         if k.startswith("sdq/") and k.endswith("alpha_w") and ("conv0" in k or "UResBlock1" in k):
             assert abs(sd[k[4:]].item() - float(g[k])) <= 1e-4 * abs(float(g[k])), k
+
+
+def test_entrance_ptq_with_a_yaml_config_and_yaml_beats_the_command_line(tmp_path, monkeypatch):
+    """Row b2: the `entrance.py ptq --config x.yaml` flow (entrance.py:17-28, 116-126).  Every NON-NULL key of the YAML
+    replaces the command-line value (quirk Q15: the file wins), null keys leave the command line alone, and keys the
+    parser does not know (the reference's configs carry data paths etc.) are simply attached to the namespace.  The
+    calibration itself runs on the oracle-backed stand-in (tests/cpu_backend.py), `device: cpu` coming from the YAML."""
+    import yaml
+    from efficientq_amd import config as Cf, entrance
+    cpu_backend.install(monkeypatch)
+    snap = str(tmp_path / "snap")
+    cfg = dict(task="lits", model="UResQ", nMod=1, nClass=3, init_stride="1", depth="1,1,1", width="8,16,8", nla="relu",
+               norm="bn", drop_rate=0.5, ds="simple", hetero_dim=True, blk="mid", init_kernel=3, qconv="effq",
+               qlvl_w=4, qlvl_a=4, q_first=None, q_last="256,-1", lwq_batchsz=2, lwq_patchsz="16,16,16", device="cpu",
+               synthetic=True, no_test=True, snap_dir=snap, data_dir="/data/lits", split_dir=None, some_new_key=7)
+    path = tmp_path / "lits_tiny_ptq.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    argv = ["ptq", "--config", str(path), "--qlvl_w", "16", "--qlvl_a", "16", "--width", "4,8,4", "--task", "brats",
+            "--q_first", "256,-1", "--q_last", "16,16", "--lwq_batchsz", "1"]
+    # the merge on its own
+    args = Cf.merge_config(str(path), Cf.build_parser().parse_args(argv))
+    assert (args.qlvl_w, args.qlvl_a, args.width, args.task, args.lwq_batchsz) == (4, 4, "8,16,8", "lits", 2)   # YAML wins
+    assert args.q_first == "256,-1"              # null in the YAML: the command line's value stays
+    assert args.q_last == "256,-1" and args.device == "cpu" and args.some_new_key == 7 and args.split_dir is None
+    # and the whole mission
+    entrance.main(argv)
+    lines = open(os.path.join(snap, "layer_loss.txt")).read().strip().split("\n")
+    assert len(lines) == 10 and lines[0].startswith(f"{'conv0.conv':45s}:")
+    for f in ("time_cost.txt", "class_voxel_nums.txt", "state_in_fp.pkl", "state_in_int8.pkl", "state_in_int8_compress.npz"):
+        assert os.path.exists(os.path.join(snap, f)), f
+    sd = torch.load(os.path.join(snap, "state_in_int8.pkl"))["state_dict"]
+    w = sd["u_blocks.UResBlock1.Layer1.block1.conv.weight"]
+    assert w.dtype == torch.uint8 and int(w.max()) <= 3 and tuple(w.shape[:2]) == (8, 8)      # 4 levels, width 8: the YAML's
+    assert int(sd["conv0.conv.weight"].max()) > 3                                             # q_first 256 from the command line
 
 
 # ------------------------------------------------------------------ data-parallel (gloo, world_size 2)

@@ -108,23 +108,132 @@ def test_wide_layer_calibration_within_reference_self_spread(gold, tag):
     print(f"{tag}: reference self-spread {sp}; hip vs t1/t8 (layer_loss, best, idx, out rel-MSE) = {rep}")
 
 
+@pytest.mark.parametrize("tag", ["s32", "s48"])
+def test_wide_layer_on_many_voxels_against_reference_and_fp64(gold, tag):
+    """The regime the bench runs in: ONE 32 -> 32 3^3 layer on V = 32^3 / 48^3 voxels of one volume
+    (V / n = 38 / 128), through the DEFAULT path (exact-integer Gram, per-iteration losses from the Gram system), against
+    the reference run with 1 and with 8 BLAS threads and the oracle's fp64 evaluation of the same arithmetic (g5e; inputs
+    rebuilt from the seed, FP target exact by construction).  What the fixture shows: more voxels do NOT make the
+    reference agree with itself - its two runs separate within the first iterations and end 3.4 - 3.8 % of the ids,
+    2.0 - 2.3e-2 output rel-MSE and 8e-4 (32^3) / 3.5e-3 (48^3) layer_loss apart, up to 1.9e-3 from the fp64 plateau.  So,
+    with FIXED bars:
+      * everything that precedes the trajectory is held to the tight bar: alpha_act 1e-6; the first proximal solve within
+        1e-5 of fp64 (reference: 5 - 7e-6); level ids of iteration 0 equal to fp64's except where the fp64 pre-image lies
+        within 1e-4 level units of a rounding boundary, at most 8 of them; loss of iteration 0 within 1e-5 + 5e-4 per such
+        id of fp64's;
+      * the plateau: layer_loss and best loss within 6e-3 of the fp64 anchor and of either reference run (the reference
+        itself: 3.5e-3 between its runs, 1.9e-3 from fp64); weight ids and quantised output within 5 % / 5e-2 rel-MSE of
+        the 8-thread run (the reference's own two runs: 3.8 % / 2.3e-2) - north_star's 1e-3 is not met by the reference
+        against itself at 32 channels at ANY voxel count, on the output or on the layer loss."""
+    from efficientq_amd.qconv import EfficientQConvHIP
+    from tests import golden_inputs as GI
+    g = gold("g5e_wide_layer_many_voxels.npz")
+    S = GI.G5E_CASES[tag]["S"]
+    inp = GI.wide_layer_inputs(S, int(g[f"{tag}_seed"]))
+    for k in ("w", "b", "x", "y", "mask"):
+        assert torch.equal(GI.checksums(inp[k]), T(g[f"{tag}_chk_{k}"])), k
+    conv = EfficientQConvHIP(32, 32, 3, 1, 1, 1, 1, True, q_weight=True, qlvl=4, q_act=True, qlvl_act=4, lwq_trace=True)
+    conv.weight.data, conv.bias.data = inp["w"].clone(), inp["b"].clone()
+    conv.output_fp, conv.name, conv.layer_loss = inp["y"], "layer", []
+    conv.mask_pyramid = [torch.ones(1, S // 2, S // 2, S // 2), inp["mask"]]
+    _to_dev(conv)
+    import efficientq_amd.qconv as Q
+    ops = Q.get_ops(torch.device(DEV))
+    runs, calls, orig = [], [], ops.admm_run
+
+    def spy(*a, **kw):
+        calls.append((a, kw))
+        runs.append(orig(*a, **kw))
+        return runs[-1]
+    ops.admm_run = spy
+    try:
+        conv.set_quantizing()
+        with torch.no_grad():
+            out = conv(inp["x"].to(DEV)).cpu()
+    finally:
+        del ops.admm_run                   # the instance attribute shadowing the method
+    torch.cuda.synchronize()
+    tr = dict(conv.last_trace)
+    assert tr["gram_loss"], "the default path of the bench's dominant layers"
+    # w*_0 (which the run overwrites) formed again from the run's operands by the entry points iteration 0 goes through
+    (A0, B0, W0, b0, geom, yn), kw = calls[0]
+    Ainv = ops.spd_inverse(A0, True, 2 * kw["rho"], kw["eta"])
+    wst, bst = torch.empty_like(W0), torch.empty_like(b0)
+    ops.prox_solve_shifted(B0, Ainv, W0, b0, W0, torch.zeros_like(W0), kw["rho"], kw["eta"], 2 * kw["rho"], wst, bst)
+    torch.cuda.synchronize()
+    tr["wstar0"] = wst
+    hist = np.array(tr["loss_history"])
+    got_ll = float(conv.layer_loss[0].split(":")[1])
+    lv = lambda t: torch.round((t / t.abs().max() + 1) * 1.5)
+    w = conv.weight.data.cpu()
+    f_hist, f_ll = g[f"{tag}_f64_loss_hist"], float(g[f"{tag}_f64_layer_loss"])
+    a64 = float(g[f"{tag}_f64_alpha_act"])
+    assert abs(conv.alpha_act.item() - a64) <= 1e-6 * a64
+    # ---- iteration 0 against fp64
+    w64 = T(g[f"{tag}_f64_wstar0"]).double()
+    ws0 = tr["wstar0"].double().cpu().reshape(w64.shape) if "wstar0" in tr else None
+    rep = {}
+    if ws0 is not None:
+        rep["w*0 vs fp64"] = ((ws0 - w64).norm() / w64.norm()).item()
+        assert rep["w*0 vs fp64"] <= 1e-5, rep
+        # level ids of iteration 0: fp64's, except on a rounding boundary
+        from oracle import effq_oracle as O
+        fit = O.fit_scale(ws0, 4, -1.0, 1.0)
+        u = (torch.clamp(ws0 / fit.alpha, -1.0, 1.0) + 1.0) / (2.0 / 3.0)
+        fit64 = O.fit_scale(w64, 4, -1.0, 1.0)
+        u64 = (torch.clamp(w64 / fit64.alpha, -1.0, 1.0) + 1.0) / (2.0 / 3.0)
+        flips = torch.round(u) != torch.round(u64)
+        margin = (u64 - torch.floor(u64) - 0.5).abs()
+        rep["iteration-0 ids off fp64"] = int(flips.sum())
+        assert int(flips.sum()) <= 8 and (not flips.any() or float(margin[flips].max()) <= 1e-4), (rep, margin[flips])
+        assert abs(hist[0] - f_hist[0]) <= (1e-5 + 5e-4 * int(flips.sum())) * f_hist[0], (hist[0], f_hist[0], rep)
+    else:
+        assert abs(hist[0] - f_hist[0]) <= 4e-3 * f_hist[0]
+    # ---- the plateau, fixed bars
+    refs = {nt: (float(g[f"{tag}_t{nt}_layer_loss"]), g[f"{tag}_t{nt}_loss_hist"].min()) for nt in (1, 8)}
+    refs["f64"] = (f_ll, f_hist.min())
+    for k, (ll, best) in refs.items():
+        rep[f"layer_loss vs {k}"] = abs(got_ll - ll) / ll
+        rep[f"best vs {k}"] = abs(hist.min() - best) / best
+        assert rep[f"layer_loss vs {k}"] <= 6e-3 and rep[f"best vs {k}"] <= 6e-3, rep
+    sub = int(g[f"{tag}_fwd_sub"])
+    rep["ids vs t8"] = (lv(w) != lv(T(g[f"{tag}_t8_weight"]))).float().mean().item()
+    rep["ids vs fp64"] = (lv(w) != T(g[f"{tag}_f64_weight_idx"]).float()).float().mean().item()
+    rep["out rel-MSE vs t8"] = _rel_mse(out[:, :, ::sub, ::sub, ::sub], T(g[f"{tag}_t8_fwd_q_sub"]))
+    print(f"{tag}: {rep}; reference t1 vs t8: ids {float(g[f'{tag}_spread_idx_mismatch']):.4f}, out rel-MSE "
+          f"{float(g[f'{tag}_spread_out_rel_mse']):.4f}, layer_loss {float(g[f'{tag}_spread_layer_loss']):.2e}")
+    assert rep["ids vs t8"] <= 5e-2 and rep["out rel-MSE vs t8"] <= 5e-2, rep
+    assert len(torch.unique(w)) <= 4
+
+
 @pytest.mark.parametrize("task,fname", [("brats", "g6_tiny_brats_L4.npz"), ("lits", "g6_tiny_lits_L4.npz"),
-                                        ("brats", "g6c_tiny_brats_L4.npz"), ("lits", "g6c_tiny_lits_L4.npz")])
+                                        ("brats", "g6c_tiny_brats_L4.npz"), ("lits", "g6c_tiny_lits_L4.npz"),
+                                        ("lits", "g6e_tiny_lits_s221_L4.npz"),
+                                        ("lits", "g6f_tiny_lits_L16.npz"), ("brats", "g6f_tiny_brats_L16.npz")])
 def test_whole_calibration_matches_reference(gold, monkeypatch, task, fname):
     """Whole do_ptq window against the reference, in both of its behaviours: g6_* = as it runs on the CPU (the hook's
     `.cpu()` aliases the conv output there, so the targets of the convs feeding an in-place ReLU are overwritten);
-    g6c_* = with the copy a GPU run makes (the product's default; tests/golden/make_goldens.py:_copying_hook)."""
+    g6c_* = with the copy a GPU run makes (the product's default; tests/golden/make_goldens.py:_copying_hook).
+    g6e = the LiTS geometry of config/lits_ptq.yaml, init_stride "2,2,1" on 64 x 64 x 32 volumes: anisotropic first conv,
+    avg_pool3d(out, (2,2,1)) at the head of the mask pyramid (ptqer.py:148-150), final up-sampling x (2,2,1).
+    g6f = 16 / 16 levels (BASELINE configs[2] arithmetic) through the whole net.  Both with the GPU hook behaviour."""
     from efficientq_amd import calibrate as K
-    monkeypatch.setattr(K, "ALIAS_FP_TARGETS", not fname.startswith("g6c"))
+    monkeypatch.setattr(K, "ALIAS_FP_TARGETS", fname.startswith("g6_"))
     g = gold(fname)
-    args, model, _ = _tiny(task)
+    L = int(g["meta"][0])
+    stride = str(g["init_stride"]) if "init_stride" in g.files else None
+    args, model, _ = _tiny(task, L=L, init_stride=stride if task == "lits" else None)
+    if stride is not None:
+        assert args.init_stride == stride
     model.load_state_dict({k[4:]: T(g[k]) for k in g.files if k.startswith("sd0/")}, strict=False)
     model.eval()
     K.search_fold_and_remove_bn(model)
     model.to(DEV)
     S = int(g["meta"][1])
+    shape = tuple(int(v) for v in g["shape"]) if "shape" in g.files else (S, S, S)
     nmod = 1 if task == "lits" else 2
-    vols = torch.randn(2, nmod, S, S, S, generator=torch.Generator().manual_seed(int(g["vols_seed"])))
+    vols = torch.randn(2, nmod, *shape, generator=torch.Generator().manual_seed(int(g["vols_seed"])))
+    assert torch.equal(vols[:, :, ::8, ::8, ::8], T(g["vols_check"]))
     if task == "brats":
         zz = torch.arange(S).float() - (S - 1) / 2
         r = (zz[:, None, None] ** 2 + zz[None, :, None] ** 2 + zz[None, None, :] ** 2).sqrt()
@@ -140,6 +249,7 @@ def test_whole_calibration_matches_reference(gold, monkeypatch, task, fname):
         assert torch.equal(m.cpu(), T(g[f"pyr{i}"]).float())
     sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4), slice(None, None, 4))
     assert torch.allclose(res["output_fp"][-1][sub].cpu(), T(g["output_fp_sub"]), atol=2e-5)
+    print(f"{fname}: layer_loss distance to the reference {np.abs(got - want) / want}")
     # first layers see identical inputs: 1e-3 relative; later layers drift with the kept plateau iterate
     assert np.all(np.abs(got[:2] - want[:2]) <= 1e-3 * want[:2]), (got, want)
     # (observed: <= 1 % on most layers, up to 8.5 % - towards the LOWER loss - on one late layer of the tiny nets)
@@ -687,38 +797,65 @@ def test_packed_weight_export_round_trip():
     assert (w_ref - w_before).abs().max() <= 0.5 * w_before.abs().max()
 
 
-def test_quantised_sliding_window_inference_and_dice_proxy(gold):
-    """Row f1: the calibrated tiny net run patch-wise in quantized mode (every conv = conv3d_quant_calib_step with
-    the activation quantiser fused), stitched like validate_seg, and scored against the FP network's predictions."""
-    from efficientq_amd import calibrate as K, evaluate as E
-    g = gold("g6c_tiny_lits_L4.npz")     # (copy semantics: the product's default)
-    args, model, _ = _tiny("lits")
-    model.load_state_dict({k[4:]: T(g[k]) for k in g.files if k.startswith("sd0/")}, strict=False)
+def test_quantised_sliding_window_inference_and_dice_proxy(gold, monkeypatch):
+    """Row f1 on the width 32,64,32 LiTS net of g6d: calibrate on the GPU, then
+      * the one-patch sliding window is the plain quantised forward, bit for bit;
+      * OVERLAPPED half-size patches run through the HIP quantised forward (every conv = conv3d_quant_calib_step with the
+        activation quantiser fused) and stitched by the product (utils/transforms.py:784-852) against the ORACLE: the same
+        calibrated weights on the CPU, every patch from oracle.split_patches through oracle conv arithmetic
+        (tests/cpu_backend.py: F.conv3d on oracle.discretize'd activations), stitched by oracle.stitch_patches.  The two
+        convs sum in different orders, so an activation within an ulp of a rounding boundary may take the other level on
+        one side (a local difference of one level step): bars = relative MSE 1e-6 and 99.9 % of the voxels within 1e-5 of
+        the largest logit;
+      * the FP-vs-quantised agreement (the Dice proxy) of the stitched output within north_star's 0.1 pt of the nearer of
+        the reference's two runs of the same calibration (g6d)."""
+    import copy
+    from efficientq_amd import calibrate as K, evaluate as E, synth
+    import efficientq_amd.qconv as Q
+    from tests import cpu_backend
+    g = gold("g6d_wide_lits_L4.npz")
+    args, model, _ = _tiny("lits", width="32,64,32")
+    synth.randomise_network(model, int(g["net_seed"]))
     model.eval()
     K.search_fold_and_remove_bn(model)
     model.to(DEV)
     S = int(g["meta"][1])
-    vols = torch.randn(2, 1, S, S, S, generator=torch.Generator().manual_seed(int(g["vols_seed"]))).to(DEV)
+    vols_cpu = torch.randn(2, 1, S, S, S, generator=torch.Generator().manual_seed(int(g["vols_seed"])))
+    assert torch.equal(vols_cpu[:, :, ::8, ::8, ::8], T(g["vols_check"]))
+    vols = vols_cpu.to(DEV)
     K.set_name(model)
-    import copy
     fp_model = copy.deepcopy(model)                        # calibration overwrites the weights in place
     res = K.calibrate_model(model, vols, "lits", args.init_stride)
     K.set_quantized(model)
+    psz, ov = S // 2, S // 8
     with torch.no_grad():
         whole = torch.stack(list(model(vols)))
-        # one patch covering the image: the sliding window is the plain quantised forward, bit for bit
         one = E.sliding_window_forward(model, vols, S, 0)
         assert torch.equal(one, whole)
         assert torch.allclose(whole[-1], res["output_q"][-1], atol=1e-5)
-        # overlapped half-size patches: finite, right shape, every voxel covered
-        sw = E.sliding_window_forward(model, vols, S // 2, S // 8)
+        sw = E.sliding_window_forward(model, vols, psz, ov)
     assert sw.shape == whole.shape and torch.isfinite(sw).all()
     dice_q, out_q, out_fp = E.fp_vs_quantised_dice(model, vols, "lits", fp_model=fp_model, patch_size=S, overlap=0)
-    assert torch.allclose(out_fp, res["output_fp"][-1], atol=2e-5)
+    assert torch.allclose(out_fp, res["output_fp"][-1], atol=2e-5 * out_fp.abs().max().item())
     dice_q2, _, _ = E.fp_vs_quantised_dice(model, vols, "lits", fp_logits=res["output_fp"][-1], patch_size=S, overlap=0)
     assert all(abs(float(a) - float(b)) <= 1e-3 for a, b in zip(dice_q, dice_q2))
     assert len(dice_q) == out_q.shape[1] and all(0.0 <= float(d) <= 1.0 for d in dice_q)
     agree = ((out_q > 0) == (out_fp > 0)).float().mean().item()
-    assert abs(agree - float(g["agree"])) <= 1e-2          # same agreement level as the calibration run itself
-    # the dominant class is segmented consistently by the 4-level network (random-init tiny net: a loose bar)
-    assert max(float(d) for d in dice_q) > 0.5
+    refs = [float(g["copy_t8/agree"]), float(g["copy_t1/agree"])]
+    assert min(abs(agree - r) for r in refs) <= 1e-3, (agree, refs)          # 0.1 pt
+    # ---- the oracle side: same weights, CPU, oracle arithmetic per patch, oracle stitching
+    sw_hip = sw.cpu()
+    cpu_model = copy.deepcopy(model).cpu()
+    cpu_backend.install(monkeypatch)
+    K.set_quantized(cpu_model)
+    with torch.no_grad():
+        preds = [torch.stack(list(cpu_model(pt.contiguous()))) for pt in O.split_patches(vols_cpu, psz, ov)]
+    want = O.stitch_patches(vols_cpu, preds, psz, ov)
+    assert want.shape == sw_hip.shape
+    d = (sw_hip - want).abs()
+    top = want.abs().max().item()
+    rel = _rel_mse(sw_hip, want)
+    q999 = torch.quantile(d.flatten()[:: max(1, d.numel() // 4_000_000)], 0.999).item()
+    print(f"stitched HIP vs oracle: rel-MSE {rel:.2e}, 99.9 % of |diff| <= {q999 / top:.2e} of the largest logit, max "
+          f"{d.max().item() / top:.2e}; agreement {agree:.5f} (reference {refs})")
+    assert rel <= 1e-6 and q999 <= 1e-5 * top, (rel, q999 / top)

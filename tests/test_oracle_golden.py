@@ -85,7 +85,7 @@ def test_g7_bn_fold(gold):
 @pytest.mark.parametrize("task", ["lits", "brats"])
 def test_g8_attention_masks(gold, task):
     g = gold("g8_attmask.npz")
-    for key, st in ((f"{task}_s1", 1), (f"{task}_s2", (2, 2, 2))):
+    for key, st in ((f"{task}_s1", 1), (f"{task}_s2", (2, 2, 2)), (f"{task}_s221", (2, 2, 1))):
         logits, data = T(g[f"{key}_logits"]), T(g[f"{key}_data"])
         ones = torch.ones_like(data[:, 0]).bool()
         body = (data[:, 0] != 0).bool() if task == "brats" else ones
@@ -228,3 +228,49 @@ def test_g11_dice_helpers(gold):
     assert torch.equal(d_b, torch.from_numpy(g["m_dice_brats"]))
     empty = O.dice(torch.zeros(4, dtype=torch.bool), torch.zeros(4, dtype=torch.bool)).float()
     assert torch.equal(empty, torch.from_numpy(g["m_dice_empty"]))
+
+
+def test_g5e_oracle_reproduces_the_reference_on_many_voxels(gold):
+    """g5e: ONE 32 -> 32 3^3 layer on V = 32^3 voxels of one volume (V / n = 38: the regime the bench runs in, against
+    V / n = 4 of g5b).  The tensors are rebuilt from the seed (tests/golden_inputs.py; the FP target is exact in fp32 by
+    construction) and must match the generator's checksums; the oracle then reproduces the reference's 8-thread run bit
+    for bit: 200 losses, final weights, layer_loss."""
+    from tests import golden_inputs as GI
+    g = gold("g5e_wide_layer_many_voxels.npz")
+    tag = "s32"
+    S = GI.G5E_CASES[tag]["S"]
+    inp = GI.wide_layer_inputs(S, int(g[f"{tag}_seed"]))
+    for k in ("w", "b", "x", "y", "mask"):
+        assert torch.equal(GI.checksums(inp[k]), T(g[f"{tag}_chk_{k}"])), k
+    assert torch.equal(inp["x"][:, ::8, ::8, ::8, ::8], T(g[f"{tag}_x_sub"]))
+    assert torch.equal(inp["y"][:, ::8, ::8, ::8, ::8], T(g[f"{tag}_y_sub"]))
+    y64 = F.conv3d(inp["x_fp"].double(), inp["w"].double(), inp["b"].double(), 1, 1)
+    assert torch.equal(inp["y"].double(), y64)                       # exact: no rounding anywhere in the FP forward
+    pyr = [torch.ones(1, S // 2, S // 2, S // 2), inp["mask"]]
+    r = O.calibrate_layer(inp["x"], inp["y"], inp["w"], inp["b"], 1, 1, qlvl_w=4, qlvl_act=4, mask_pyramid=pyr)
+    assert np.array_equal(np.array(r.loss_history), g[f"{tag}_t8_loss_hist"])
+    assert r.layer_loss == float(g[f"{tag}_t8_layer_loss"])
+    assert torch.equal(r.weight, T(g[f"{tag}_t8_weight"]))
+    assert torch.equal(r.wstar0, T(g[f"{tag}_t8_wstar0"]))
+
+
+def test_g5e_reference_does_not_agree_with_itself_on_many_voxels_either(gold):
+    """What the g5e fixture establishes (VERDICT r3 expected the opposite): with V >> n the reference's runs with 1 and
+    with 8 BLAS threads still separate within the first iterations and end 3 - 4 % of the weight ids and 2 % output
+    rel-MSE apart - the same distances as on the 12^3 layers of g5b - and even the plateau VALUE (layer_loss) differs by
+    8e-4 (32^3) and 3.5e-3 (48^3: north_star's 1e-3 is missed by the reference against itself).  The discrete ADMM
+    trajectory amplifies a single flipped weight whatever the conditioning of the system."""
+    g = gold("g5e_wide_layer_many_voxels.npz")
+    for tag in ("s32", "s48"):
+        a, b = g[f"{tag}_t1_loss_hist"], g[f"{tag}_t8_loss_hist"]
+        wa, wb = T(g[f"{tag}_t1_weight"]), T(g[f"{tag}_t8_weight"])
+        lv = lambda t: torch.round((t / t.abs().max() + 1) * 1.5)
+        idx = (lv(wa) != lv(wb)).float().mean().item()
+        assert abs(idx - float(g[f"{tag}_spread_idx_mismatch"])) < 1e-12
+        assert 0.02 < idx < 0.05
+        assert 1e-2 < float(g[f"{tag}_spread_out_rel_mse"]) < 5e-2
+        assert 5e-4 < float(g[f"{tag}_spread_layer_loss"]) < 5e-3
+        assert np.max(np.abs(a - b) / b) > 0.1                       # the transients differ by > 10 % somewhere
+        # and both runs leave the fp64 trajectory within a few iterations as well
+        f = g[f"{tag}_f64_loss_hist"]
+        assert np.max(np.abs(b[:30] - f[:30]) / f[:30]) > 1e-3 and np.max(np.abs(a[:30] - f[:30]) / f[:30]) > 1e-3
