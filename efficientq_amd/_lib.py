@@ -94,8 +94,6 @@ SIGNATURES = {
     "effq_alpha_fixed_point": (_I, [_P, _SZ, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
     "effq_fp_small_max": (_SZ, []),
     "effq_fixed_point_small": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P]),
-    "effq_fp_sorted_max": (_SZ, []),
-    "effq_fixed_point_sorted": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P]),
     "effq_fp_coop_max": (_SZ, []),
     "effq_fp_coop_set_spin_limit": (_I, [C.c_uint]),
     "effq_fixed_point_coop": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _P]),
@@ -142,6 +140,7 @@ SIGNATURES = {
     "effq_pack_levels": (_I, [_P, _SZ, _I, _P, _P]),
     "effq_unpack_levels": (_I, [_P, _SZ, _I, _P, _P]),
     "effq_ainv_ld": (_I, [_I]),
+    "effq_admm_uses_traj": (_I, [_SZ, _I]),
     "effq_spd_inverse_ws_bytes": (_SZ, [_I]),
     "effq_spd_inverse": (_I, [_P, _I, _I, _D, _D, _P, _P, _SZ, _P]),
     "effq_prox_ws_bytes": (_SZ, [_I, _I]),

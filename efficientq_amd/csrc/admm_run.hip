@@ -178,6 +178,15 @@ using namespace effq;
 
 extern "C" {
 
+// whether effq_admm_run would use effq_fixed_point_traj for a layer of nw weights at w_levels levels (the caller then
+// provides fp_pred / fp_traj_ws; otherwise both may be NULL)
+int effq_admm_uses_traj(size_t nw, int w_levels) {
+  static const bool traj_on = !(getenv("EFFQ_FP_TRAJ") && atoi(getenv("EFFQ_FP_TRAJ")) == 0);
+  static const int traj_levels = getenv("EFFQ_FP_TRAJ_LEVELS") ? atoi(getenv("EFFQ_FP_TRAJ_LEVELS")) : 4;
+  static const size_t traj_min = getenv("EFFQ_FP_TRAJ_MIN") ? (size_t)atoll(getenv("EFFQ_FP_TRAJ_MIN")) : 65536;
+  return (traj_on && w_levels <= traj_levels && nw >= traj_min && nw <= effq_fp_traj_max()) ? 1 : 0;
+}
+
 int effq_admm_num_inverses(double rho, double rho_max, int iters, int period) {
   if (!(rho > 0.0) || iters <= 0 || period <= 0) return -1;
   const RhoPlan p = plan_rhos(rho, rho_max, iters, period);
@@ -222,17 +231,13 @@ int effq_admm_run(const effq_admm_run_args* a) {
   // 743; from 5 / 10 / 15 iterations after a change of rho, layers of 65 536 ... 2^20 weights only: 702 / 703 / 699; and
   // for larger layers from 30 iterations after: 698).  The iterations in between run the kernels above, which leave
   // their iterates behind.  EFFQ_FP_TRAJ=0, EFFQ_FP_TRAJ_AFTER[_BIG], EFFQ_FP_TRAJ_MIN, EFFQ_FP_TRAJ_LEVELS: A/B switches
-  static const bool traj_on = !(getenv("EFFQ_FP_TRAJ") && atoi(getenv("EFFQ_FP_TRAJ")) == 0);
   static const bool traj_rho_old = !(getenv("EFFQ_FP_TRAJ_RHO") && atoi(getenv("EFFQ_FP_TRAJ_RHO")) == 0);
   // (at 16 levels the fixed point takes ~50 iterations: the one hull slot for everything past the seventh keeps a third
   // of the values on the list, and the older kernels are faster - measured, scripts/prof_fp_traj.py)
-  static const int traj_levels = getenv("EFFQ_FP_TRAJ_LEVELS") ? atoi(getenv("EFFQ_FP_TRAJ_LEVELS")) : 4;
   static const int traj_after_env = getenv("EFFQ_FP_TRAJ_AFTER") ? atoi(getenv("EFFQ_FP_TRAJ_AFTER")) : 12;
   static const int traj_after_big = getenv("EFFQ_FP_TRAJ_AFTER_BIG") ? atoi(getenv("EFFQ_FP_TRAJ_AFTER_BIG")) : 30;
-  static const size_t traj_min = getenv("EFFQ_FP_TRAJ_MIN") ? (size_t)atoll(getenv("EFFQ_FP_TRAJ_MIN")) : 65536;
   const int traj_after = (nw > ((size_t)1 << 20)) ? traj_after_big : traj_after_env;
-  const bool traj = traj_on && a->fp_pred != nullptr && a->fp_traj_ws != nullptr && a->w_levels <= traj_levels && nw >= traj_min &&
-                    nw <= effq_fp_traj_max();
+  const bool traj = a->fp_pred != nullptr && a->fp_traj_ws != nullptr && effq_admm_uses_traj(nw, a->w_levels) != 0;
   if (traj && a->fp_traj_ws_bytes < effq_fp_traj_ws_bytes(nw)) {
     set_error("admm_run: trajectory fixed-point workspace %zu < %zu", a->fp_traj_ws_bytes, effq_fp_traj_ws_bytes(nw));
     return EFFQ_ERR_WORKSPACE;

@@ -90,6 +90,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---- DPP reductions over groups of GS lanes (GS a power of two <= 64); every lane of a 16-lane row ends with the
 // row's total, groups of 32 / 64 are finished with readlane.  Fixed tree: deterministic for fp64 too.
+// INVARIANT: every lane of a group that enters the tree must be active (for wave_sum_f64_dpp and gs = 64: all 64
+// lanes; for smaller groups: whole, aligned groups - a wave may have some groups switched off, never part of one).
+// A DPP move whose source lane is switched off in EXEC returns `old` (0 here), so the partial sums that lane should have
+// carried through the xor / mirror butterfly are lost to every lane that reads from it.  The removed sorted-value fixed
+// point (round 3: "wrong totals at one boundary per lane, right totals with four boundary slots per lane or an
+// unconditional re-sum") is that pattern: the variants that gave right totals are exactly those that entered the tree
+// with all 64 lanes.  The call sites of this library: whole waves (operands of absent elements set to 0, not their
+// lanes switched off), or - fpb_iterate - groups of gs lanes that are active or inactive as a whole.
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);

@@ -6,12 +6,13 @@
 // single ones and the hull of the tail - each with two relative margins: a NARROW one (2.5 x the last drift) and a WIDE
 // one (the envelope of the recent drifts: they are noisy).  The level of a value is monotone in the scale
 // (fixed_point_bracket.hip), so:
-//   phase 1, all workgroups, one pass: v = a + b is formed and stored; every value is classified at the two ends of the
-//     hull of all wide brackets - equal levels (3 of 4 values): it adds (level * u, level, level^2) to the hull tally,
-//     u = rint(v * 2^e) - and otherwise, per slot j, at the ends of the wide bracket (equal -> wide tally of slot j) and
-//     of the narrow one (equal -> ring tally of slot j and bit j of the value's ring mask; different -> bit j of its
-//     narrow mask).  Values with a narrow bit go to the narrow list (a fraction of a per cent), values with ring bits
-//     only to the ring list (a few per cent);
+//   phase 1, all workgroups, one pass: v = a + b is formed and stored; every value is classified, per slot j, at the
+//     two ends of the wide bracket - equal levels: it adds (level * u, level, level^2) to the wide tally of slot j,
+//     u = rint(v * 2^e) - and otherwise at the ends of the narrow one (equal -> ring tally of slot j and bit j of the
+//     value's ring mask; different -> bit j of its narrow mask).  Values with a narrow bit go to the narrow list (a
+//     fraction of a per cent), values with ring bits only to the ring list (a few per cent).  The unit 2^-e comes from
+//     the PREVIOUS call's sum|v|: should |v| have grown so much that the tallies wrap (they are summed mod 2^64, in
+//     unsigned arithmetic: no undefined behaviour), phase 2 notices (tallies_ok) and every iterate takes the full pass;
 //   phase 2, the last workgroup to finish: sum|v| (partials in workgroup order: deterministic) gives alpha_0; iterate i
 //     inside its narrow bracket costs a scan of the narrow list (held in registers) on top of three tallies; inside the
 //     wide bracket only, a scan of both lists; outside both, a pass of this one workgroup over all of v (slow, rare:
@@ -74,6 +75,11 @@ __device__ __forceinline__ long long fpt_wave_sum(long long v) {
   return (long long)(((unsigned long long)l2 << 42) + ((unsigned long long)l1 << 21) + (unsigned long long)l0);
 }
 __device__ __forceinline__ long long fpt_pack(int r) { return (long long)r + ((long long)(r * r) << 32); }
+// acc + level * u mod 2^64 (the unit of u is a PREDICTION: a tensor that grew by more than ~4 x since the last call
+// can wrap the sum, which phase 2 detects and discards - but it must not be signed overflow)
+__device__ __forceinline__ long long fpt_add_wrap(long long acc, int level, long long u) {
+  return (long long)((unsigned long long)acc + (unsigned long long)(long long)level * (unsigned long long)u);
+}
 
 __global__ __launch_bounds__(FPT_T) void k_fpt(const float* __restrict__ a, const float* __restrict__ b2,
                                                float* __restrict__ v_out, size_t n, FptWs w, FptPred* pred,
@@ -169,12 +175,12 @@ __global__ __launch_bounds__(FPT_T) void k_fpt(const float* __restrict__ a, cons
           if (j < K) {
             const int ra = level_end(v, 4 * j), rb = level_end(v, 4 * j + 3);
             if (ra == rb) {
-              tw_ru[j] += (long long)ra * u;
+              tw_ru[j] = fpt_add_wrap(tw_ru[j], ra, u);
               tw_ct[j] += fpt_pack(ra);
             } else {
               const int na = level_end(v, 4 * j + 1), nb = level_end(v, 4 * j + 2);
               if (na == nb) {
-                tr_ru[j] += (long long)na * u;
+                tr_ru[j] = fpt_add_wrap(tr_ru[j], na, u);
                 tr_ct[j] += fpt_pack(na);
                 rmask |= 1u << j;
               } else {
@@ -487,6 +493,8 @@ int effq_fixed_point_traj(const float* a, const float* b, float* v_out, size_t n
   EFFQ_CHECK_ARG(a && state_dev && pred_dev && ws && n > 0 && levels >= 2 && levels <= 16 && hi > lo && max_iter > 0);
   EFFQ_CHECK_ARG(n <= FPT_MAXN);
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
+  // k_fpt declares its operands __restrict__ and its last workgroup re-reads v_out (or a) after other workgroups wrote it
+  EFFQ_CHECK_ARG(v_out == nullptr || (v_out != a && v_out != b));
   if (ws_bytes < fpt_ws_bytes(n)) {
     set_error("fixed_point_traj: workspace %zu < %zu bytes", ws_bytes, fpt_ws_bytes(n));
     return EFFQ_ERR_WORKSPACE;

@@ -379,251 +379,6 @@ __global__ __launch_bounds__(T) void k_fp_small(const float* __restrict__ a, con
   }
 }
 
-// ---- whole project_by_iter on SORTED values, for many-level quantisers on small tensors ------------------------
-// At 256 levels (first / last conv, q_first = q_last = "256,-1") the fixed point takes ~300 iterations per call and is
-// called 200 times per layer: the per-iteration LATENCY is what counts (k_fp_small: 1.3 us = per-value work + two wave
-// reductions + a workgroup barrier + two fp64 divisions).  Here the values are sorted once (bitonic, LDS) with fp64
-// prefix sums P[i] = sum of the i smallest; the level function is monotone in v, so the values of level index >= k
-// start at a position pos_k, and
-//     sum r v = (L-1) P[n] - sum_k P[pos_k],   sum r = (L-1) n - sum_k pos_k,   sum r^2 = (L-1)^2 n - sum_k (2k-1) pos_k
-// (k = 1..L-1) feed the same expressions as k_fp_small.  ONE wave iterates, lane = boundary (KB per lane): no barrier,
-// no cross-wave traffic.  pos_k is re-found from its previous value: the boundaries creep as alpha converges, so almost
-// every check is "still between the same two neighbours" (two LDS reads); otherwise a galloping + binary search.
-// The predicate "level index of v >= k" is the fp32 evaluation of u = (v/alpha - lo)/d unless u lies within 2e-4 of the
-// rounding boundary k - 1/2, where the reference's own fp64 arithmetic (disc64) decides: positions - and therefore
-// the integer sums - are exactly the reference's; sum r v differs from a sequential fp64 sum by rounding order only.
-constexpr int FPSORT_T = 1024;
-constexpr int FPSORT_MAXN = 4096;
-
-template <int KB>
-__global__ __launch_bounds__(FPSORT_T) void k_fp_sorted(const float* __restrict__ a, const float* __restrict__ b2,
-                                                        float* __restrict__ v_out, int n, int P, int levels,
-                                                        effq_fp_state* st, double lo, double hi, double d, double tol,
-                                                        int max_iter) {
-  __shared__ float sv[FPSORT_MAXN];
-  __shared__ double pre[FPSORT_MAXN + 1];
-  __shared__ double part[2][FPSORT_T / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  // ---- load v = a + b2, sum |v| ----
-  double acc0 = 0.0;
-  for (int i = tid; i < P; i += FPSORT_T) {
-    float v = __builtin_inff();
-    if (i < n) {
-      v = (b2 != nullptr) ? (a[i] + b2[i]) : a[i];
-      if (v_out != nullptr) v_out[i] = v;
-      acc0 += fabs((double)v);
-    }
-    sv[i] = v;
-  }
-  acc0 = wave_sum_f64_dpp(acc0);
-  if (lane == 0) part[0][wid] = acc0;
-  __syncthreads();
-  double tot = 0.0;
-#pragma unroll
-  for (int w = 0; w < FPSORT_T / 64; ++w) tot += part[0][w];
-  // ---- bitonic sort, ascending (the +inf padding ends up behind the n values) ----
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (P >> 1); t += FPSORT_T) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-        const bool up = (i & k) == 0;
-        const float x = sv[i], y = sv[l];
-        if ((x > y) == up) {
-          sv[i] = y;
-          sv[l] = x;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // ---- fp64 prefix sums pre[i] = sum of the i smallest values: thread t owns the chunk [t C, (t+1) C); the chunk
-  // totals are scanned (Hillis-Steele, fixed order) in two scratch rows taken from `pre`, which is written afterwards
-  {
-    const int C = (P + FPSORT_T - 1) / FPSORT_T;         // 1, 2 or 4 (P is a power of two >= 64)
-    const int nch = P / C;                               // <= 1024 chunks
-    double loc = 0.0;
-    if (tid < nch)
-      for (int q = 0; q < C; ++q) {
-        const int i = tid * C + q;
-        if (i < n) loc += (double)sv[i];
-      }
-    double* src = pre;
-    double* dst = pre + FPSORT_T;
-    if (tid < nch) src[tid] = loc;
-    __syncthreads();
-    for (int off = 1; off < nch; off <<= 1) {
-      if (tid < nch) dst[tid] = src[tid] + (tid >= off ? src[tid - off] : 0.0);
-      __syncthreads();
-      double* sw = src;
-      src = dst;
-      dst = sw;
-    }
-    const double excl = (tid < nch && tid > 0) ? src[tid - 1] : 0.0;    // total of the chunks before this one
-    __syncthreads();                                     // every scan value has been read: pre may be overwritten
-    if (tid < nch) {
-      double run = excl;
-      for (int q = 0; q < C; ++q) {
-        const int i = tid * C + q;
-        if (i <= n) pre[i] = run;
-        if (i < n) run += (double)sv[i];
-      }
-      if (tid * C + C == n) pre[n] = run;                // (n == P, or n at a chunk end: same value as the next chunk's)
-    }
-    __syncthreads();
-  }
-  if (wid != 0) return;
-  // ---- the fixed point, one wave ----
-  __builtin_amdgcn_s_setprio(3);
-  const int L1 = levels - 1;
-  const double rd = 1.0 / d;
-  const float c0 = (float)(-lo * rd);
-  double alpha = tot / (double)n, alpha_prev = -999.0;
-  float c1 = (float)(((double)n / tot) * rd);
-  auto pred = [&](int i, int kidx) -> bool {             // level index of the i-th smallest value >= kidx ?
-    if (i < 0) return false;
-    if (i >= n) return true;
-    const float vf = sv[i];
-    const float u = __builtin_fmaf(vf, c1, c0);
-    const float thr = (float)kidx - 0.5f;
-    if (fabsf(u - thr) > 2e-4f) return u > thr;           // (NaN: falls through to the exact path)
-    double r;
-    disc64((double)vf, alpha, lo, hi, d, &r);
-    return r >= (double)kidx;
-  };
-  // Per boundary the lane keeps its position and the two values around it, vlo = v[pos - 1] and vhi = v[pos], in
-  // registers.  An iteration first asks, without touching memory, whether each boundary is CERTAINLY still between its
-  // two neighbours: the fp32 evaluation of u puts vhi more than 2e-4 level units above the rounding boundary and vlo
-  // more than 2e-4 below it (the same test pred() accepts without the exact arithmetic).  Only the boundaries that
-  // fail it are searched again - each lane takes one of its failing boundaries per pass, so a pass costs one search
-  // however many lanes take part - with pred() (exact) from the old position.
-  constexpr float F_INF = __builtin_huge_valf();
-  int pos[KB];
-  float vlo[KB], vhi[KB];
-#pragma unroll
-  for (int kk = 0; kk < KB; ++kk) {
-    const int kidx = 1 + lane + 64 * kk;
-    int lo_i = -1, hi_i = n;                             // pred(lo_i) false, pred(hi_i) true
-    if (kidx <= L1)
-      while (hi_i - lo_i > 1) {
-        const int mid = (lo_i + hi_i) >> 1;
-        if (pred(mid, kidx)) hi_i = mid; else lo_i = mid;
-      }
-    pos[kk] = hi_i;
-    vlo[kk] = (kidx <= L1 && hi_i > 0) ? sv[hi_i - 1] : -F_INF;
-    vhi[kk] = (kidx <= L1 && hi_i < n) ? sv[hi_i] : F_INF;
-  }
-  const double svt = pre[n];
-  const double lo_sv = lo * svt, lo2n = lo * lo * (double)n, d2 = d * d, dlo2 = 2.0 * d * lo;
-  const double rv_top = (double)L1 * svt;
-  const double r_top = (double)L1 * (double)n, r2_top = (double)L1 * (double)L1 * (double)n;
-  // this lane's share of sum_k P[pos_k] and of the integer sums sum_k pos_k, sum_k (2k-1) pos_k (the two packed into one
-  // double: 2^22 * sr2 + sr stays below 2^53), recomputed only when one of its positions moves
-  constexpr double PACK = 4194304.0;                     // 2^22 > sum_k pos_k (<= 255 * 4096)
-  double sp = 0.0, spk = 0.0;
-  auto lane_sums = [&]() {
-    sp = 0.0;
-    unsigned sr = 0, sr2 = 0;
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk) {
-      const int kidx = 1 + lane + 64 * kk;
-      if (kidx <= L1) {
-        const int p = pos[kk];
-        sp += pre[p];
-        sr += (unsigned)p;
-        sr2 += (unsigned)((2 * kidx - 1) * p);
-      }
-    }
-    spk = (double)sr2 * PACK + (double)sr;
-  };
-  lane_sums();
-  double last0 = 0.0, last1 = 0.0;
-  int it = 0, done = 0;
-  while (!done) {
-    const double wsp = wave_sum_f64_dpp(sp);
-    const double wpk = wave_sum_f64_dpp(spk);              // exact: integers below 2^53
-    const double wr2 = floor(wpk * (1.0 / PACK));
-    const double wr = wpk - wr2 * PACK;
-    const double trv = rv_top - wsp;
-    const double tr = r_top - wr, tr2 = r2_top - wr2;
-    const double t0 = d * trv + lo_sv;                         // sum b v
-    const double t1 = (d2 * tr2 + dlo2 * tr) + lo2n;           // sum b^2
-    const double a_new = t0 / t1;
-    const double ra_new = t1 / t0;                             // independent of the division above (pipelines with it)
-    ++it;
-    if (it >= max_iter)
-      done = 2;
-    else if (!(fabs(a_new - alpha) > tol))
-      done = 1;
-    alpha_prev = alpha;
-    alpha = a_new;
-    last0 = t0;
-    last1 = t1;
-    if (done) break;
-    c1 = (float)(ra_new * rd);
-    // which boundaries are not certainly in place under the new alpha (registers only)
-    unsigned need = 0;
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk) {
-      const float thr = (float)(1 + lane + 64 * kk) - 0.5f;
-      const bool ok = (__builtin_fmaf(vhi[kk], c1, c0) - thr > 2e-4f) && (thr - __builtin_fmaf(vlo[kk], c1, c0) > 2e-4f);
-      need |= ok ? 0u : (1u << kk);
-    }
-    bool moved = false;
-    while (need != 0u) {                                   // one failing boundary of this lane per pass
-      const int k = __builtin_ctz(need);
-      need &= need - 1u;
-      const int kidx = 1 + lane + 64 * k;
-      int p = pos[0];
-#pragma unroll
-      for (int kk = 1; kk < KB; ++kk) p = (k == kk) ? pos[kk] : p;
-      int lo_i, hi_i;
-      if (pred(p, kidx)) {                                 // pos <= p: gallop down
-        hi_i = p;
-        lo_i = p - 1;
-        int step = 1;
-        while (lo_i >= 0 && pred(lo_i, kidx)) {
-          hi_i = lo_i;
-          lo_i -= step;
-          step <<= 1;
-        }
-        if (lo_i < -1) lo_i = -1;
-      } else {                                             // pos > p: gallop up
-        lo_i = p;
-        hi_i = p + 1;
-        int step = 1;
-        while (hi_i < n && !pred(hi_i, kidx)) {
-          lo_i = hi_i;
-          hi_i += step;
-          step <<= 1;
-        }
-        if (hi_i > n) hi_i = n;
-      }
-      while (hi_i - lo_i > 1) {
-        const int mid = (lo_i + hi_i) >> 1;
-        if (pred(mid, kidx)) hi_i = mid; else lo_i = mid;
-      }
-      moved = moved || (hi_i != p);
-      const float nlo = (hi_i > 0) ? sv[hi_i - 1] : -F_INF;
-      const float nhi = (hi_i < n) ? sv[hi_i] : F_INF;
-#pragma unroll
-      for (int kk = 0; kk < KB; ++kk) {
-        pos[kk] = (k == kk) ? hi_i : pos[kk];
-        vlo[kk] = (k == kk) ? nlo : vlo[kk];
-        vhi[kk] = (k == kk) ? nhi : vhi[kk];
-      }
-    }
-    if (moved) lane_sums();
-  }
-  if (lane == 0) {
-    st->alpha = alpha;
-    st->alpha_prev = alpha_prev;
-    st->sums[0] = last0;
-    st->sums[1] = last1;
-    st->iters = it;
-    st->done = done;
-  }
-}
-
 // ---- cooperative whole-fixed-point kernel for larger tensors --------------------------------------
 // G <= 256 workgroups of 1024 threads, one per CU, each owning a contiguous slice of v that stays in LDS for
 // all iterations.  Per iteration every workgroup publishes its two partial sums, all meet at a grid
@@ -642,6 +397,15 @@ static unsigned g_fpc_spin_limit = FPC_SPIN_LIMIT;     // effq_fp_coop_set_spin_
 // out.  A poisoned workspace turns every later launch into a no-op that reports done = 3 (the launches of the following
 // ADMM iterations are already enqueued when a time-out happens, and the arrival counter is left non-zero by the early
 // exits: they must not run on it); the host clears the workspace when it sees the error (qconv.ptq).
+// INVARIANT of the exchange through fpc_barrier: whatever workgroups hand to each other across it is WRITTEN with
+// fpc_publish (agent-scope atomic store: write-through, no stale line left in the writer's L2) before the barrier and
+// READ with agent-scope atomic loads after it - never with plain loads: the barrier issues a release fence but NO acquire
+// fence (see below), so a plain load could be served from this CU's L1.  The lock-step of data-parallel replicas rests
+// on this (tests/test_configs_gpu.py: test_config2_at_its_stated_size_is_deterministic, in the default GPU selection).
+__device__ __forceinline__ void fpc_publish(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ bool fpc_barrier(unsigned int* counter, unsigned target, int* s_fail, unsigned spin_limit) {
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -728,9 +492,9 @@ __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, cons
   unsigned epoch = 0;
   // partials layout: [parity][wg][3]
   if (tid == 0) {
-    partials[(0 * FPC_MAXG + wg) * 3 + 0] = acc0;
-    partials[(0 * FPC_MAXG + wg) * 3 + 1] = acc1;
-    partials[(0 * FPC_MAXG + wg) * 3 + 2] = 0.0;
+    fpc_publish(&partials[(0 * FPC_MAXG + wg) * 3 + 0], acc0);
+    fpc_publish(&partials[(0 * FPC_MAXG + wg) * 3 + 1], acc1);
+    fpc_publish(&partials[(0 * FPC_MAXG + wg) * 3 + 2], 0.0);
   }
   if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail, spin_limit)) {
     if (tid == 0) st->done = 3;          // (any workgroup: workgroup 0 may have left through the poison check)
@@ -795,9 +559,9 @@ __global__ __launch_bounds__(T) void k_fp_coop(const float* __restrict__ a, cons
     double dr = (double)sr, dr2 = (double)sr2;
     wg_sum3(arv, dr, dr2);
     if (tid == 0) {
-      partials[(par * FPC_MAXG + wg) * 3 + 0] = arv;
-      partials[(par * FPC_MAXG + wg) * 3 + 1] = dr;
-      partials[(par * FPC_MAXG + wg) * 3 + 2] = dr2;
+      fpc_publish(&partials[(par * FPC_MAXG + wg) * 3 + 0], arv);
+      fpc_publish(&partials[(par * FPC_MAXG + wg) * 3 + 1], dr);
+      fpc_publish(&partials[(par * FPC_MAXG + wg) * 3 + 2], dr2);
     }
     if (!fpc_barrier(counter, (++epoch) * (unsigned)G, &s_fail, spin_limit)) {
       if (tid == 0) st->done = 3;
@@ -1091,23 +855,6 @@ int effq_alpha_fixed_point(const float* x, size_t n, int levels, double lo, doub
 }
 
 size_t effq_fp_small_max(void) { return (size_t)1 << 15; }
-size_t effq_fp_sorted_max(void) { return (size_t)FPSORT_MAXN; }
-
-int effq_fixed_point_sorted(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
-                            double tol, int max_iter, effq_fp_state* state_dev, void* stream) {
-  EFFQ_CHECK_ARG(a && state_dev && n > 0 && levels >= 2 && levels <= 256 && hi > lo && max_iter > 0);
-  EFFQ_CHECK_ARG(n <= effq_fp_sorted_max());
-  EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
-  const double d = (hi - lo) / (double)(levels - 1);
-  int P = 64;
-  while ((size_t)P < n) P <<= 1;
-  // one instantiation (4 boundary slots per lane of the iterating wave cover 255 boundaries; unused slots are skipped)
-  hipLaunchKernelGGL((k_fp_sorted<4>), dim3(1), dim3(FPSORT_T), 0, as_stream(stream), a, b, v_out, (int)n, P, levels,
-                     state_dev, lo, hi, d, tol, max_iter);
-  EFFQ_LAUNCH_CHECK();
-  return EFFQ_OK;
-}
-
 int effq_fixed_point_small_fused(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                                  double tol, int max_iter, effq_fp_state* state_dev, const ProjFused* pf_in, void* stream);
 
@@ -1127,10 +874,6 @@ int effq_fixed_point_small_fused(const float* a, const float* b, float* v_out, s
   EFFQ_CHECK_ARG(n <= effq_fp_small_max());
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
   const double d = (hi - lo) / (double)(levels - 1);
-  // many levels on a small tensor: the sorted-value kernel (effq_fixed_point_sorted) where it is the faster one
-  static const int sorted_on = getenv("EFFQ_FP_SORTED") ? atoi(getenv("EFFQ_FP_SORTED")) : 0;   // A/B switch
-  if (sorted_on && pf.G == nullptr && levels >= 32 && levels <= 256 && n <= (size_t)FPSORT_MAXN)
-    return effq_fixed_point_sorted(a, b, v_out, n, levels, lo, hi, tol, max_iter, state_dev, stream);
   {
     // threads: 256 up to 2048 elements, 512 up to 16384 (few waves: the barrier is cheap and the element loop stays
     // short; measured best on MI355X, scripts/exp_fp256.py), else 1024; slots per thread rounded up to a power of 2.  EFFQ_FPS_T overrides (tuning aid).
@@ -1188,6 +931,7 @@ int effq_fixed_point_coop_rec(const float* a, const float* b, float* v_out, size
   EFFQ_CHECK_ARG(a && state_dev && ws && n > 0 && levels >= 2 && hi > lo && max_iter > 0);
   EFFQ_CHECK_ARG(n <= effq_fp_coop_max());
   EFFQ_CHECK_ARG(b == nullptr || v_out != nullptr);
+  EFFQ_CHECK_ARG(v_out == nullptr || (v_out != a && v_out != b));      // k_fp_coop's operands are __restrict__
   const double d = (hi - lo) / (double)(levels - 1);
   int G = (int)((n + FPC_SLICE - 1) / FPC_SLICE);
   if (G < 1) G = 1;

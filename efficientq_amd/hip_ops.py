@@ -293,11 +293,6 @@ class HipOps:
         _, it, _ = self.fit_scale(v, levels, -1.0, 1.0, guess_iters=guess, state=state)
         return it
 
-    def fixed_point_sorted(self, a, b, v, levels: int, state, lo: float = -1.0, hi: float = 1.0):
-        """project_by_iter of v = a + b on sorted values, one launch (effq_fixed_point_sorted; <= 4096 values)."""
-        check(self.lib.effq_fixed_point_sorted(_ptr(a), _ptr(b), _ptr(v), a.numel(), levels, lo, hi, ADMM_TOL,
-                                               100 * levels, _ptr(state), self.stream), "effq_fixed_point_sorted")
-
     def fixed_point_bucket(self, a, b, v, levels: int, state, lo: float = -1.0, hi: float = 1.0):
         """project_by_iter of v = a + b (b may be None) on the bucketed copy: one workgroup, one launch
         (effq_fixed_point_bucket)."""
@@ -603,7 +598,7 @@ class HipOps:
         fpw = (self._workspace("fp_bucket", self.lib.effq_fp_bucket_ws_bytes(nw))
                if nw <= self.lib.effq_fp_bucket_max() and BUCKET_FIXED_POINT else None)
         # weight projection from the previous iteration's iterates (effq_fixed_point_traj)
-        traj = TRAJ_FIXED_POINT and levels <= 16 and 16384 <= nw <= self.lib.effq_fp_traj_max()   # (the library decides)
+        traj = TRAJ_FIXED_POINT and bool(self.lib.effq_admm_uses_traj(nw, int(levels)))   # the library's own decision
         tws = self._workspace("fp_traj", self.lib.effq_fp_traj_ws_bytes(nw)) if traj else None
         r.fp_pred = torch.zeros(self.lib.effq_fp_traj_pred_bytes(), dtype=torch.uint8, device=dev) if traj else None
         if loss_kind == 4:

@@ -108,13 +108,6 @@ int effq_alpha_fixed_point(const float* x, size_t n, int levels, double lo, doub
 size_t effq_fp_small_max(void);
 int effq_fixed_point_small(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
                            double tol, int max_iter, effq_fp_state* state_dev, void* stream);
-/* Same contract on SORTED values (n <= effq_fp_sorted_max() = 4096, levels <= 256): the values are sorted once with fp64
- * prefix sums; one wave iterates with a lane per level boundary, re-finding each boundary's position from its previous
- * one.  Level counts are exactly the reference's; meant for many-level quantisers (the 256-level weights of the first /
- * last conv, ~300 iterations per call).  effq_fixed_point_small dispatches here when EFFQ_FP_SORTED=1. */
-size_t effq_fp_sorted_max(void);
-int effq_fixed_point_sorted(const float* a, const float* b, float* v_out, size_t n, int levels, double lo, double hi,
-                            double tol, int max_iter, effq_fp_state* state_dev, void* stream);
 /* Same contract for larger tensors (n <= effq_fp_coop_max()): one COOPERATIVE launch of ceil(n/27648) <= 256
  * workgroups (one per CU, slice of v resident in LDS) that meet at a bounded-spin grid barrier once per
  * iteration; partial sums are combined in workgroup order by every workgroup (deterministic).  state.done = 3
@@ -384,7 +377,7 @@ typedef struct effq_admm_run_args {
   void* prox_ws; size_t prox_ws_bytes;
   void* red_ws;
   void* fp_ws; size_t fp_ws_bytes;
-  /* effq_fixed_point_traj for the weight projection (levels <= 16, 16384 <= weights <= effq_fp_traj_max()): fp_pred =
+  /* effq_fixed_point_traj for the weight projection (where effq_admm_uses_traj(weights, w_levels) says so): fp_pred =
    * effq_fp_traj_pred_bytes() of device memory (the run zero-fills it), fp_traj_ws = effq_fp_traj_ws_bytes(weights),
    * zero-filled once.  NULL: the older fixed points only. */
   void* fp_pred; void* fp_traj_ws; size_t fp_traj_ws_bytes;
@@ -395,7 +388,11 @@ typedef struct effq_admm_run_args {
   /* optional second side stream with its own inverse workspace: the later inverses alternate between the two side
    * streams (their serial pivot phases overlap); NULL: one side stream */
   void* stream_side2; void* inv_ws_side2; size_t inv_ws_side2_bytes;
-  /* loss_kind 4: the loss of an iterate from the layer's unweighted Gram system (effq_gram_loss): Au [n][n], Bu [c2][n]
+  /* 1 if effq_admm_run takes the trajectory weight projection (effq_fixed_point_traj) for a layer of nw weights at
+ * w_levels levels - the caller then passes fp_pred (effq_fp_traj_pred_bytes(), zero-filled) and fp_traj_ws
+ * (effq_fp_traj_ws_bytes(nw)); otherwise both may be NULL and nothing needs to be allocated. */
+int effq_admm_uses_traj(size_t nw, int w_levels);
+/* loss_kind 4: the loss of an iterate from the layer's unweighted Gram system (effq_gram_loss): Au [n][n], Bu [c2][n]
    * (effq_gram_accum_i8_unw), syy = one device double, sum y^2 over this rank's voxels; conv_ws = effq_gram_loss_ws_bytes(n)
    * zero-filled once.  NULL for the other kinds. */
   const double* loss_Au; const double* loss_Bu; const double* loss_syy;

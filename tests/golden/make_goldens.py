@@ -575,7 +575,10 @@ def run_do_ptq(task, L, S, width="8,16,8", copy_targets=False, threads=8, seed=6
     return dict(ll=ll, nums=nums, outs=outs, captured=captured, sd0=sd0, vols=vols, L=L, S=S)
 
 
-def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_targets=False, lits_stride="1"):
+def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_targets=False, lits_stride="1",
+       second_run_threads=None):
+    """second_run_threads: also run the reference with that many BLAS threads and store its layer losses and FP-vs-Q
+    agreement (`t1_*`): the reference's own reproducibility floor for this case."""
     r = run_do_ptq(task, L, S, copy_targets=copy_targets, lits_stride=lits_stride)
     ll, nums, outs, captured, sd0, vols = r["ll"], r["nums"], r["outs"], r["captured"], r["sd0"], r["vols"]
     sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4), slice(None, None, 4))
@@ -588,6 +591,14 @@ def g6(task="lits", L=4, S=16, tag="g6_tiny_lits_L4", brats_zero=False, copy_tar
            "layer_loss": np.array([float(l.split(":")[1]) for l in ll], dtype=np.float64),
            "class_nums": np.array(nums, dtype=np.int64),
            "meta": np.array([L, _shape3(S)[0]]), "shape": np.array(_shape3(S)), "init_stride": np.array(lits_stride if task == "lits" else "2,2,2")}
+    if second_run_threads:
+        r2 = run_do_ptq(task, L, S, copy_targets=copy_targets, lits_stride=lits_stride, threads=second_run_threads)
+        o2 = r2["outs"]
+        out["t1_layer_loss"] = np.array([float(l.split(":")[1]) for l in r2["ll"]], dtype=np.float64)
+        out["t1_agree"] = np.float64(((o2[0][-1] > 0) == (o2[1][-1] > 0)).float().mean().item())
+        out["t1_threads"] = np.int64(second_run_threads)
+        print(tag, "reference self-spread: layer_loss", np.abs(out["t1_layer_loss"] - out["layer_loss"]) / out["layer_loss"],
+              "agreement", float(out["agree"]), float(out["t1_agree"]))
     for i, p in enumerate(captured["pyr"]):
         out[f"pyr{i}"] = p.to(torch.uint8)
         assert (p == p.to(torch.uint8).float()).all()
@@ -842,11 +853,11 @@ if __name__ == "__main__":
     if "g6e" in which:
         # LiTS geometry: init_stride "2,2,1" through the real do_ptq, GPU hook behaviour
         # (the pyramid pools five more times after the initial stride, ptqer.py:154-167: the strided axes need 64 voxels)
-        g6("lits", 4, (64, 64, 32), "g6e_tiny_lits_s221_L4", copy_targets=True, lits_stride="2,2,1")
+        g6("lits", 4, (64, 64, 32), "g6e_tiny_lits_s221_L4", copy_targets=True, lits_stride="2,2,1", second_run_threads=1)
     if "g6f" in which:
         # configs[2] arithmetic on a whole net: 16 / 16 levels, GPU hook behaviour
-        g6("lits", 16, 32, "g6f_tiny_lits_L16", copy_targets=True)
-        g6("brats", 16, 64, "g6f_tiny_brats_L16", copy_targets=True)
+        g6("lits", 16, 32, "g6f_tiny_lits_L16", copy_targets=True, second_run_threads=1)
+        g6("brats", 16, 64, "g6f_tiny_brats_L16", copy_targets=True, second_run_threads=1)
     if "g6d" in which:
         g6d()
     if "g6d_lits" in which:

@@ -128,3 +128,41 @@ def test_run_to_run_identical_bits_and_wrong_predictions_are_harmless(ops):
     a, it, done = ops.read_fp_state(st)
     fit = O.fit_scale((w * 3.0 + du).cpu(), 4, -1, 1)
     assert done == 1 and it == fit.iters and abs(a - fit.alpha) <= 1e-11 * fit.alpha
+
+
+@pytest.mark.parametrize("scale", [8.0, 64.0, 1.0 / 64.0])
+def test_predictions_of_a_tensor_of_another_magnitude_fall_back_to_the_full_pass(ops, scale):
+    """phase 1 tallies level * u with the unit of the PREVIOUS call's sum|v|.  A tensor that grew 8 x / 64 x since
+    (or shrank 64 x: every bracket misses) must cost nothing but speed: the tallies are summed mod 2^64 in unsigned
+    arithmetic (no signed overflow), phase 2 discards them where they could have wrapped, every iterate takes the full
+    pass, and the result is the older fixed point's."""
+    n, L = 442368, 4
+    gen = torch.Generator().manual_seed(99)
+    base = dev(_clustered(n, gen))
+    du = dev(torch.randn(n, generator=gen) * 0.002)
+    pred, st = ops.new_fp_pred(), ops.new_fp_state()
+    v = torch.empty_like(base)
+    for _ in range(3):                                  # warm predictions on the unscaled tensor
+        ops.fixed_point_traj(base, du, v, L, st, pred)
+    before = ops.read_fp_pred(pred)
+    w2, du2 = base * scale, du * scale
+    ops.fixed_point_traj(w2, du2, v, L, st, pred)
+    a, it, done = ops.read_fp_state(st)
+    a_old, it_old, v_old = _old(ops, w2, du2, L)
+    assert done == 1 and it == it_old and abs(a - a_old) <= 1e-13 * a_old, (a, a_old, it, it_old)
+    assert torch.equal(v, v_old)
+    after = ops.read_fp_pred(pred)
+    assert after["full_iters"] - before["full_iters"] >= it - 1, (before, after)      # the predictions were worth nothing
+    # and the next call on the scaled tensor is warm again
+    ops.fixed_point_traj(w2, du2, v, L, st, pred)
+    a3, it3, done3 = ops.read_fp_state(st)
+    assert done3 == 1 and it3 == it_old and abs(a3 - a_old) <= 1e-13 * a_old
+
+
+def test_aliased_output_is_rejected(ops):
+    """k_fpt's operands are __restrict__ and its last workgroup re-reads v: v_out must not alias a or b."""
+    from efficientq_amd._lib import EffqError
+    w = dev(torch.randn(32768) * 0.05)
+    du = dev(torch.randn(32768) * 0.01)
+    with pytest.raises(EffqError):
+        ops.fixed_point_traj(w, du, w, 4, ops.new_fp_state(), ops.new_fp_pred())

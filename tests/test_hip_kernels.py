@@ -808,16 +808,18 @@ def test_bucketed_fixed_point_on_adversarial_values(ops, L):
 
 
 def _run_small(ops, x, du, L):
+    """The all-values single-workgroup kernel k_fp_small (effq_fixed_point_small): the many-level path of the product (the
+    sorted-value kernel these cases were written for was removed in round 4: 3 x slower)."""
     v = torch.empty(x.numel(), device="cuda:0")
     st = ops.new_fp_state()
-    ops.fixed_point_sorted(dev(x), None if du is None else dev(du), v, L, st)
+    ops.weight_fixed_point(dev(x), dev(du if du is not None else torch.zeros_like(x)), v, L, st)
     return ops.read_fp_state(st), v
 
 
 @pytest.mark.parametrize("L", [32, 64, 100, 256])
 @pytest.mark.parametrize("n", [1, 63, 96, 864, 3456, 4096])
-def test_sorted_value_fixed_point_matches_oracle(ops, n, L):
-    """k_fp_sorted (many levels, <= 4096 values: the 256-level weights of the first / last conv): alpha <= 1e-11 of the
+def test_many_level_fixed_point_matches_oracle(ops, n, L):
+    """k_fp_small at many levels (<= 4096 values: the 256-level weights of the first / last conv): alpha <= 1e-11 of the
     fp64 restatement of project_by_iter (layer_helper.py:40-70), SAME iteration count, v = w* + dual stored."""
     gen = torch.Generator().manual_seed(n * 7 + L)
     w = torch.randn(n, generator=gen) * 0.07
@@ -836,10 +838,10 @@ def test_sorted_value_fixed_point_matches_oracle(ops, n, L):
 
 
 @pytest.mark.parametrize("L", [64, 256])
-def test_sorted_value_fixed_point_on_adversarial_values(ops, L):
+def test_many_level_fixed_point_on_adversarial_values(ops, L):
     """Values ON rounding boundaries of the converged and of the start scale (and one ulp either side), zeros, signed
-    zeros, denormals, duplicates, an outlier, all-equal / two-valued tensors: positions found by the galloping search
-    must be exactly the reference's level counts."""
+    zeros, denormals, duplicates, an outlier, all-equal / two-valued tensors: the level counts
+    must be exactly the reference's."""
     gen = torch.Generator().manual_seed(4321 + L)
     base = torch.randn(3000, generator=gen) * 0.1
     fit0 = O.fit_scale(base, L, -1, 1)
