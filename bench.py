@@ -117,6 +117,20 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def _pmc_mfma_busy():
+    """SQ_VALU_MFMA_BUSY_CYCLES share of the prox GEMM measured alone (scripts/pmc_prox.sh -> profiles/*_pmc_prox/summary.txt,
+    line `mfma_busy_frac <value>`): the newest committed summary, or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_prox", "summary.txt")), reverse=True):
+        try:
+            for line in open(path):
+                if line.startswith("mfma_busy_frac"):
+                    return float(line.split()[1])
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def build_model(levels, device, net="brats"):
     from efficientq_amd import calibrate as K, config as Cf, synth
     args = Cf.make_args(Cf.BRATS_NET if net == "brats" else Cf.LITS_NET, levels, levels)
@@ -137,7 +151,8 @@ class OpTimer:
     iteration).  The largest single-kernel op of the critical path is the dominant kernel; its roofline uses the
     ALGORITHMIC work of one launch over the average duration."""
 
-    KIND = {1: "prox", 2: "fixed_point", 3: "project", 4: "loss", 5: "inverse"}
+    KIND = {1: "prox", 2: "fixed_point", 3: "project", 4: "loss", 5: "inverse", 6: "wait"}
+    LEVELS = 4          # activation levels of the run (set by main)
 
     def __init__(self):
         self.rec = {}
@@ -186,8 +201,15 @@ class OpTimer:
             _lib.check(lib.effq_prof_read(i, C.byref(r)), "effq_prof_read")
             g = r.geom
             kind = self.KIND[r.kind]
+            if kind == "wait":
+                self.wait_ms = getattr(self, "wait_ms", 0.0) + r.ms
+                continue
             if kind == "loss" and r.loss_kind == 4:
                 key = ("gram_loss@loop", r.c2, r.n)
+            elif kind == "loss" and r.loss_kind == 5:
+                # one record = one GROUP of iterates (k_gl8 + k_gl8_finish); every second group is bracketed
+                V = g.N * g.D * g.H * g.W
+                key = ("gram_loss_i8@loop", r.c2, r.n, V)
             elif kind == "loss":
                 name = {0: "conv_step", 1: "conv_step_i8", 2: "conv_step_i8s"}[r.loss_kind] + "@loop"
                 key = (name, g.N, g.C1, g.C2, g.D, g.H, g.W, g.KD, g.SD)
@@ -211,7 +233,14 @@ class OpTimer:
                         f"k_conv3d_i8s ({c1}->{c2}, {k}^3/s{s}, {N}x{od}x{oh}x{ow} voxels: 4*c2 B of target + c1 B of "
                         f"level ids per input voxel, i8 MFMA exact)")
             if op == "conv_step_i8":
-                return ("hbm", 4.0 * c2 * V + 1.0 * c1 * Vin, PEAK_HBM_GBS, "GB/s",
+                ops_i8, byts = 2.0 * c2 * c1 * k ** 3 * V, 4.0 * c2 * V + 1.0 * c1 * Vin
+                if ops_i8 / byts > PEAK_I8_MFMA_TOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+                    # beyond the ridge (629 op/B): the wide layers on small volumes are bound by the i8 matrix cores and the
+                    # L2 stream of their weights, not by HBM (128 -> 128 at 16^3 has ~1400 op/B)
+                    return ("mfma", ops_i8, PEAK_I8_MFMA_TOPS, "TOP/s",
+                            f"k_conv3d_i8 ({c1}->{c2}, 3^3, {N}x{od}x{oh}x{ow} voxels: 2 c2 c1 27 V int8 op, exact; "
+                            f"{ops_i8 / byts:.0f} op per HBM byte)")
+                return ("hbm", byts, PEAK_HBM_GBS, "GB/s",
                         f"k_conv3d_i8 ({c1}->{c2}, 3^3, {N}x{od}x{oh}x{ow} voxels: 4*c2 B of target + c1 B of level "
                         f"ids per voxel, i8 MFMA exact)")
             n = c1 * k ** 3 + 1
@@ -220,6 +249,15 @@ class OpTimer:
                         f"k_gram_i8 (n={n}, {V} voxels; n^2 V (upper triangle) + 8 c2 n V int8 op, exact)")
             return ("mfma", 2.0 * n * n * V + 2.0 * c2 * n * V, PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                     f"k_gram (n={n}, {V} voxels; 2n^2V+2c2nV flop, upper triangle computed)")
+        if op == "gram_loss_i8":
+            c2, n, V = key[1:]
+            nw, grp = n - 1, int(os.environ.get("EFFQ_LOSS_GROUP", "8"))
+            P = 1
+            while (1 << (8 * P - 1)) - 1 < (OpTimer.LEVELS - 1) ** 2 * V:        # effq_gram_loss_i8_num_planes
+                P += 1
+            return ("mfma", 2.0 * P * grp * c2 * nw * (nw + 256) / 2.0, PEAK_I8_MFMA_TOPS, "TOP/s",
+                    f"k_gl8 + k_gl8_finish (c2={c2}, n={n}: losses of {grp} iterates per launch from the integer Gram system, "
+                    f"{P} digit planes x {grp} x c2 nw (nw + 256) int8 op on the upper triangle, exact)")
         c2, n = key[1:]
         if op == "gram_loss":
             return ("mfma", 2.0 * c2 * n * n, PEAK_F64_MFMA_TFLOPS, "TFLOP/s",
@@ -262,6 +300,8 @@ class OpTimer:
         for key, ms in self.lib_ms.items():
             if key[0] == "inverse":
                 launches, stream = len(ms), "side"
+            elif key[0] == "gram_loss_i8@loop":
+                launches, stream = len(ms) * 2, "loss"
             else:
                 launches, stream = len(ms) * SAMPLE, ("loss" if key[0].endswith("@loop") else "main")
             items.append((key, ms, launches, stream))
@@ -279,7 +319,7 @@ class OpTimer:
                              traffic_source=(tr["source"] if tr else None), launches=launches,
                              timed_launches=len(ms), avg_ms=round(avg, 4), total_ms=round(avg * launches, 1),
                              ms_per_step=round(avg * launches / steps, 1), work_per_launch=work,
-                             composite=(key[0] in ("inverse", "fixed_point") or
+                             composite=(key[0] in ("inverse", "fixed_point", "gram_loss_i8@loop") or
                                         (key[0] == "prox" and not (key[1] > 64 and key[2] >= 1024)))))
         rows.sort(key=lambda r: -r["total_ms"])
         for r in rows:
@@ -477,6 +517,7 @@ def main():
     log(f"[rank {rank}] {a.vols} synthetic volumes {nmod}x{a.size}^3 in HBM ({time.time() - t:.1f}s)")
 
     ops = get_ops(device)
+    OpTimer.LEVELS = a.levels
     timer = OpTimer()
 
     def one_step():
@@ -522,7 +563,9 @@ def main():
                                        "frac": round(alg / (roof["avg_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                        "note": "2 c2 n^2 flop of the fp32 product per launch; round 2 ran it on the f32 "
                                                "matrix cores at 0.55 of their peak"}
-            roof["mfma_busy_frac_alone"] = 0.44
+            busy_alone = _pmc_mfma_busy()
+            if busy_alone is not None:
+                roof["mfma_busy_frac_alone"] = busy_alone          # read from the committed PMC summary, not a literal
             roof["note"] = ("frac = executed bf16 MFMA flop / dense bf16 peak quoted at 2.4 GHz; the chip holds 1.5 - 1.7 GHz "
                             "in dense bf16 loops on random data (MI355X_MICROARCH.md, DVFS give-back)")
     # 24.55 TFLOP per 4x128^3 BraTS volume, 99.69 per 1x160^3 LiTS volume (conv x 201 + Gram), scaled by voxels
@@ -558,6 +601,10 @@ def main():
                                          "not a roofline fraction - most of that work is not executed on this path"},
         # share of the wall clock the ops bracketed on each stream account for (loss and side overlap main)
         "stream_busy_frac": {k: round(v * 1e-3 / dt, 3) for k, v in busy.items()},
+        # measured WITHOUT a profiler: HIP-event pairs on the main stream around every point where the chain waits for another
+        # stream (the inverse of the next rho, the joins that end a layer), summed over the timed steps
+        "main_queue_wait": {"ms_per_step": round(getattr(timer, "wait_ms", 0.0) / a.steps, 2),
+                            "frac_of_step": round(getattr(timer, "wait_ms", 0.0) * 1e-3 / dt, 4)},
     }
     solo = rank == 0 and world == 1
     if solo and exact and not a.no_conv_subrun and _Q.GRAM_LOSS_DEFAULT:

@@ -69,7 +69,8 @@ class AdmmRunArgs(C.Structure):
                 ("conv_ws", C.c_void_p), ("conv_ws_bytes", C.c_size_t),
                 ("stream_main", C.c_void_p), ("stream_loss", C.c_void_p), ("stream_side", C.c_void_p),
                 ("stream_side2", C.c_void_p), ("inv_ws_side2", C.c_void_p), ("inv_ws_side2_bytes", C.c_size_t),
-                ("loss_Au", C.c_void_p), ("loss_Bu", C.c_void_p), ("loss_syy", C.c_void_p)]
+                ("loss_Au", C.c_void_p), ("loss_Bu", C.c_void_p), ("loss_syy", C.c_void_p),
+                ("loss_planes", C.c_void_p), ("loss_nplanes", C.c_int32)]
 
 
 class ProfRecord(C.Structure):
@@ -141,6 +142,12 @@ SIGNATURES = {
     "effq_unpack_levels": (_I, [_P, _SZ, _I, _P, _P]),
     "effq_ainv_ld": (_I, [_I]),
     "effq_admm_uses_traj": (_I, [_SZ, _I]),
+    "effq_gram_loss_i8_supported": (_I, [_I, _I, _I, _I]),
+    "effq_gram_loss_i8_num_planes": (_I, [C.c_longlong]),
+    "effq_gram_loss_i8_planes_bytes": (_SZ, [_I, _I, _I]),
+    "effq_gram_loss_i8_prepare": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P]),
+    "effq_gram_loss_i8_ws_bytes": (_SZ, []),
+    "effq_gram_loss_i8": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     "effq_spd_inverse_ws_bytes": (_SZ, [_I]),
     "effq_spd_inverse": (_I, [_P, _I, _I, _D, _D, _P, _P, _SZ, _P]),
     "effq_prox_ws_bytes": (_SZ, [_I, _I]),

@@ -46,7 +46,9 @@ struct ProfRec {
 };
 static thread_local std::vector<ProfRec> g_prof;
 static thread_local int g_prof_every = 0;
-enum { PROF_PROX = 1, PROF_FIXED_POINT = 2, PROF_PROJECT = 3, PROF_LOSS = 4, PROF_INVERSE = 5 };
+// PROF_WAIT brackets the points where the MAIN stream waits for another stream (the inverse of the next rho, the joins
+// at the end of the layer): two records on the main stream around the wait = the time the chain stood still there
+enum { PROF_PROX = 1, PROF_FIXED_POINT = 2, PROF_PROJECT = 3, PROF_LOSS = 4, PROF_INVERSE = 5, PROF_WAIT = 6 };
 
 struct ProfScope {          // records e0 now, e1 at close()
   bool on;
@@ -200,9 +202,13 @@ int effq_admm_run(const effq_admm_run_args* a) {
                  a->err_flag && a->ainv_pool && a->prox_ws && a->red_ws && a->inv_ws && a->conv_ws && a->y_fp);
   EFFQ_CHECK_ARG(a->c2 > 0 && a->n > 1 && a->iters > 0 && a->rho_period > 0 && a->w_levels >= 2 && a->w_levels <= 256);
   EFFQ_CHECK_ARG((a->has_bias != 0) == (a->b0 != nullptr) && (a->has_bias != 0) == (a->b_ring != nullptr));
-  EFFQ_CHECK_ARG((a->loss_kind >= 0 && a->loss_kind <= 2) || a->loss_kind == 4);
+  EFFQ_CHECK_ARG((a->loss_kind >= 0 && a->loss_kind <= 2) || a->loss_kind == 4 || a->loss_kind == 5);
   if (a->loss_kind == 4)
     EFFQ_CHECK_ARG(a->loss_Au != nullptr && a->loss_Bu != nullptr && a->loss_syy != nullptr);
+  else if (a->loss_kind == 5)
+    EFFQ_CHECK_ARG(a->loss_Au != nullptr && a->loss_Bu != nullptr && a->loss_syy != nullptr && a->loss_planes != nullptr &&
+                   a->loss_nplanes > 0 && a->Gq_ring != nullptr && a->act_alpha_dev != nullptr &&
+                   effq_gram_loss_i8_supported(a->c2, a->n, a->has_bias, a->w_levels));
   else
     EFFQ_CHECK_ARG(a->loss_kind == 0 ? (a->xq != nullptr) : (a->xidx != nullptr && a->Gq_ring != nullptr &&
                                                             a->act_alpha_dev != nullptr));
@@ -388,7 +394,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
   // the cheap losses from the Gram system travel in larger groups than the conv passes.  EFFQ_LOSS_GROUP[_CONV]: A/B switches
   static const int group_gram = getenv("EFFQ_LOSS_GROUP") ? atoi(getenv("EFFQ_LOSS_GROUP")) : 8;
   static const int group_conv = getenv("EFFQ_LOSS_GROUP_CONV") ? atoi(getenv("EFFQ_LOSS_GROUP_CONV")) : 4;
-  const int group_env = (a->loss_kind == 4) ? group_gram : group_conv;
+  const int group_env = (a->loss_kind == 4 || a->loss_kind == 5) ? group_gram : group_conv;
   const int loss_group = (fork_loss && group_env > 1) ? group_env : 1;
   int loss_next = 0;
   bool rho_changed_last = false;
@@ -401,7 +407,11 @@ int effq_admm_run(const effq_admm_run_args* a) {
       int r = first;
       while (r < plan.count && plan.rho[r] != rho) ++r;
       EFFQ_CHECK_ARG(r < plan.count);
-      if (fork_side && ev_inv[r] != nullptr) ADMM_HIP(hipStreamWaitEvent(s_main, ev_inv[r], 0));
+      if (fork_side && ev_inv[r] != nullptr) {
+        ProfScope p_wait(g_prof_every > 0, PROF_WAIT, i, a, s_main);
+        ADMM_HIP(hipStreamWaitEvent(s_main, ev_inv[r], 0));
+        p_wait.close();
+      }
       Ainv = a->ainv_pool + (size_t)(r - first) * ainv_elems;
       cur = r;
     }
@@ -509,7 +519,19 @@ int effq_admm_run(const effq_admm_run_args* a) {
       ADMM_HIP(hipEventRecord(e, s_main));
       ADMM_HIP(hipStreamWaitEvent(s_loss, e, 0));
     }
-    if (!fork_loss || (i + 1) % loss_group == 0 || i + 1 == a->iters) {
+    if (a->loss_kind == 5 && (!fork_loss || (i + 1) % loss_group == 0 || i + 1 == a->iters)) {
+      // the whole group in one launch pair (the digit planes of the Gram system are read once per group)
+      for (int j = loss_next; j <= i; j += 16) {
+        const int cnt = (i - j + 1 < 16) ? (i - j + 1) : 16;
+        ProfScope p_loss(g_prof_every > 0 && (j / loss_group) % 2 == 1, PROF_LOSS, j, a, s_loss);
+        ADMM_RC(effq_gram_loss_i8(a->loss_planes, a->loss_nplanes, a->loss_Au, a->loss_Bu, a->loss_syy,
+                                  a->Gq_ring + (size_t)j * nw, has_b ? a->b_ring + (size_t)j * c2 : nullptr, a->state_ring + j,
+                                  a->act_alpha_dev, a->act_levels, a->w_levels, c2, n, has_b, cnt, a->hist + 2 * (size_t)j,
+                                  a->conv_ws, a->conv_ws_bytes, s_loss));
+        p_loss.close();
+      }
+      loss_next = i + 1;
+    } else if (!fork_loss || (i + 1) % loss_group == 0 || i + 1 == a->iters) {
       for (int j = loss_next; j <= i; ++j) {
         const float* Gj = a->G_ring + (size_t)j * nw;
         const int8_t* Gqj = a->Gq_ring ? a->Gq_ring + (size_t)j * nw : nullptr;
@@ -543,6 +565,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
   }
   if (!side_enqueued) ADMM_RC(enqueue_side_inverses());      // (fewer iterations than SIDE_AFTER_ITERS)
   // join: everything the caller reads next (hist, rings) is ordered on the main stream
+  ProfScope p_join(g_prof_every > 0 && (fork_loss || fork_side), PROF_WAIT, a->iters, a, s_main);
   if (fork_loss) {
     ADMM_HIP(new_event(&ev_join_loss));
     ADMM_HIP(hipEventRecord(ev_join_loss, s_loss));
@@ -559,6 +582,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
       ADMM_HIP(hipStreamWaitEvent(s_main, ev_join_side2, 0));
     }
   }
+  p_join.close();
   destroy_events();
 #undef ADMM_HIP
 #undef ADMM_RC

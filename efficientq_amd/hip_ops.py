@@ -475,6 +475,40 @@ class HipOps:
                                       _ptr(sqerr), _ptr(ws), ws.numel(), self.stream), "effq_gram_loss")
         return sqerr
 
+    def gram_loss_i8_supported(self, c2: int, n: int, has_b: bool, w_levels: int) -> bool:
+        return bool(self.lib.effq_gram_loss_i8_supported(int(c2), int(n), int(has_b), int(w_levels)))
+
+    def gram_loss_i8_planes(self, Au: torch.Tensor, has_b: bool, act_alpha: torch.Tensor, act_levels: int, voxels: int):
+        """Balanced base-256 digit planes of K = Aww / s_a^2 (effq_gram_loss_i8_prepare): [P][round_up(nw, 256)][nw] int8.
+        `voxels` bounds the entries: K <= (act_levels - 1)^2 * voxels.  Returns None if they need more than 6 planes."""
+        n = int(Au.shape[0])
+        P = self.lib.effq_gram_loss_i8_num_planes(int((act_levels - 1) ** 2 * voxels))
+        if P < 1:
+            return None
+        nw = n - int(has_b)
+        planes = torch.empty(P, (nw + 255) // 256 * 256, nw, dtype=torch.int8, device=self.device)
+        assert planes.numel() == self.lib.effq_gram_loss_i8_planes_bytes(n, int(has_b), P)
+        err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        al = self._f32(act_alpha.reshape(1))
+        check(self.lib.effq_gram_loss_i8_prepare(_ptr(Au), n, int(has_b), _ptr(al), int(act_levels), P, _ptr(planes),
+                                                 _ptr(err), self.stream), "effq_gram_loss_i8_prepare")
+        planes._effq_err = err           # read with the layer's one host read (admm_read) or by the caller
+        return planes
+
+    def gram_loss_i8(self, planes, Au, Bu, syy, Gq, b, states, act_alpha, act_levels: int, w_levels: int, hist=None):
+        """Losses of `count` stacked iterates (Gq [count, c2, nw] int8, b [count, c2], states [count, 5] fp64)."""
+        count, c2 = int(Gq.shape[0]), int(Bu.shape[0])
+        n = int(Bu.shape[1])
+        has_b = b is not None
+        if hist is None:
+            hist = torch.zeros(count, 2, dtype=torch.float64, device=self.device)
+        ws = self._workspace("gram_loss_i8", self.lib.effq_gram_loss_i8_ws_bytes())
+        al = self._f32(act_alpha.reshape(1))
+        check(self.lib.effq_gram_loss_i8(_ptr(planes), int(planes.shape[0]), _ptr(Au), _ptr(Bu), _ptr(syy), _ptr(Gq), _ptr(b),
+                                         _ptr(states), _ptr(al), int(act_levels), int(w_levels), c2, n, int(has_b), count,
+                                         _ptr(hist), _ptr(ws), ws.numel(), self.stream), "effq_gram_loss_i8")
+        return hist
+
     def gram_reduce(self, A0: torch.Tensor, B0: torch.Tensor, reducer):
         """Data-parallel SUM of a layer's Gram system as ONE message: upper triangle of A0 + B0 (effq_gram_pack)."""
         n, c2 = int(A0.shape[0]), int(B0.shape[0])
@@ -564,9 +598,14 @@ class HipOps:
         xq = self._f32(xq) if xq is not None else None
         nw = W0.numel()
         y = self._f32(y_ndhwc)
-        if loss_gram is not None:
+        planes = None
+        if loss_gram is not None and len(loss_gram) == 4:
+            loss_kind = 5                         # (Au, Bu, syy, planes): the same with the quadratic form on the i8 cores
+            planes = loss_gram[3]
+            loss_gram = loss_gram[:3]
+        elif loss_gram is not None:
             loss_kind = 4                         # (Au, Bu, syy): losses from the unweighted Gram system
-        _check_shapes(geom, xq if loss_kind in (0, 4) else xidx, W0, b0, y)
+        _check_shapes(geom, xq if loss_kind in (0, 4, 5) else xidx, W0, b0, y)
         if tuple(A0.shape) != (n, n) or nw != c2 * (n - int(has_b)):
             raise _lib.EffqError("admm_run: A0/B0/W0 shapes do not match")
         n_inv = self.lib.effq_admm_num_inverses(float(rho), float(rho_max), int(iters), int(period))
@@ -580,7 +619,7 @@ class HipOps:
         r.wstar = torch.empty(nw, dtype=f32, device=dev)
         r.v = torch.empty(nw, dtype=f32, device=dev)
         r.G_ring = torch.empty(iters, nw, dtype=f32, device=dev)
-        r.Gq_ring = torch.empty(iters, nw, dtype=torch.int8, device=dev) if loss_kind in (1, 2) else None
+        r.Gq_ring = torch.empty(iters, nw, dtype=torch.int8, device=dev) if loss_kind in (1, 2, 5) else None
         r.b_ring = torch.empty(iters, c2, dtype=f32, device=dev) if has_b else None
         r.state_ring = torch.zeros(iters, 5, dtype=torch.float64, device=dev)
         r.hist = torch.zeros(iters, 2, dtype=torch.float64, device=dev)
@@ -601,7 +640,9 @@ class HipOps:
         traj = TRAJ_FIXED_POINT and bool(self.lib.effq_admm_uses_traj(nw, int(levels)))   # the library's own decision
         tws = self._workspace("fp_traj", self.lib.effq_fp_traj_ws_bytes(nw)) if traj else None
         r.fp_pred = torch.zeros(self.lib.effq_fp_traj_pred_bytes(), dtype=torch.uint8, device=dev) if traj else None
-        if loss_kind == 4:
+        if loss_kind == 5:
+            cws = self._workspace("gram_loss_i8", self.lib.effq_gram_loss_i8_ws_bytes())
+        elif loss_kind == 4:
             cws = self._workspace("gram_loss", self.lib.effq_gram_loss_ws_bytes(n))
         elif loss_kind == 1:
             cws = self._workspace("conv_i8", self.lib.effq_conv_i8_ws_bytes(C.byref(geom)))
@@ -610,7 +651,7 @@ class HipOps:
                                                                              int(levels)))
         else:
             cws = self._workspace("conv", self.lib.effq_conv_ws_bytes(C.byref(geom)))
-        al = self._f32(act_alpha.reshape(1)) if (act_alpha is not None and loss_kind in (1, 2)) else None
+        al = self._f32(act_alpha.reshape(1)) if (act_alpha is not None and loss_kind in (1, 2, 5)) else None
         a = _lib.AdmmRunArgs()
         p = lambda t: None if t is None else t.data_ptr()
         a.A0, a.B0, a.W0, a.b0 = p(A0), p(B0), p(W0), p(b0)
@@ -621,12 +662,15 @@ class HipOps:
         a.loss_kind, a.act_levels = int(loss_kind), int(act_levels)
         a.xq = p(xq) if loss_kind == 0 else None
         a.xidx = p(xidx) if loss_kind in (1, 2) else None
-        if loss_kind == 4:
+        if loss_kind in (4, 5):
             Au, Bu, syy = loss_gram
             if (Au.dtype != torch.float64 or Bu.dtype != torch.float64 or syy.dtype != torch.float64 or
                     tuple(Au.shape) != (n, n) or tuple(Bu.shape) != (c2, n) or syy.numel() != 1):
                 raise _lib.EffqError("admm_run: loss_gram wants fp64 (Au [n,n], Bu [c2,n], syy [1])")
             a.loss_Au, a.loss_Bu, a.loss_syy = p(Au), p(Bu), p(syy)
+            if loss_kind == 5:
+                a.loss_planes, a.loss_nplanes = p(planes), int(planes.shape[0])
+                r.loss_planes = planes
         a.y_fp, a.act_alpha_dev = p(y), p(al)
         a.dual, a.wstar, a.v = p(r.dual), p(r.wstar), p(r.v)
         a.G_ring, a.Gq_ring, a.b_ring = p(r.G_ring), p(r.Gq_ring), p(r.b_ring)
@@ -663,7 +707,10 @@ class HipOps:
     def admm_read(run, best, extra=None):
         """ONE device->host copy per layer: loss history, best, the last scale, fixed-point iteration counts, error
         (and `extra`, a small fp64 device tensor the caller wants read in the same copy)."""
-        parts = [run.hist[:, 0], best, run.state_ring[-1, :1], run.state_ring[:, 4], run.err.to(torch.float64)]
+        err = run.err.to(torch.float64)
+        if getattr(run, "loss_planes", None) is not None:       # effq_gram_loss_i8_prepare's flag: 1000 x (1 | 2)
+            err = err + 1000.0 * run.loss_planes._effq_err.to(torch.float64)
+        parts = [run.hist[:, 0], best, run.state_ring[-1, :1], run.state_ring[:, 4], err]
         if extra is not None:
             parts.append(extra.to(torch.float64).reshape(-1))
         pack = torch.cat(parts).cpu()

@@ -30,6 +30,7 @@ OVERLAP_LOSS_DEFAULT = _os.environ.get("EFFQ_OVERLAP_LOSS", "1") != "0"
 # per-iteration losses from the unweighted Gram system (effq_gram_loss) for layers with n = k^3 c1 + 1 up to this size
 GRAM_LOSS_DEFAULT = _os.environ.get("EFFQ_GRAM_LOSS", "1") != "0"
 GRAM_LOSS_MAX_N = int(_os.environ.get("EFFQ_GRAM_LOSS_MAX_N", "1729"))
+GRAM_LOSS_I8 = _os.environ.get("EFFQ_GRAM_LOSS_I8", "1") != "0"     # wide layers: the quadratic form on the i8 matrix cores
 
 
 def get_ops(device):
@@ -352,10 +353,17 @@ class EfficientQConvHIP(PTQConv):
         loss_gram = None
         use_gl = bool(use_gi8 and GRAM_LOSS_DEFAULT and hasattr(ops, "gram_loss") and n_sys <= GRAM_LOSS_MAX_N and
                       yn.numel() // c2 >= 8 * n_sys)
-        if use_gi8 and use_gl:
+        # ... and on the wide layers (n above GRAM_LOSS_MAX_N: the fp64 evaluation would cost more than the conv pass) with
+        # the quadratic form on the i8 matrix cores: both of its factors are small integers there (effq_gram_loss_i8)
+        use_gl8 = bool(use_gi8 and GRAM_LOSS_DEFAULT and GRAM_LOSS_I8 and not use_gl and n_sys > GRAM_LOSS_MAX_N and
+                       getattr(ops, "gram_loss_i8_supported", lambda *a: False)(c2, n_sys, has_b, self.qlvl_w))
+        if use_gi8 and (use_gl or use_gl8):
             A0, B0, Au, Bu = ops.gram_i8(xidx, att_cls, yn, geom, has_b, self.alpha_act.data, self.qlvl_act,
                                          unweighted=True)
             loss_gram = (Au, Bu, syy_local)
+            if use_gl8:
+                planes = ops.gram_loss_i8_planes(Au, has_b, self.alpha_act.data, self.qlvl_act, yn.numel() // c2)
+                loss_gram = (Au, Bu, syy_local, planes) if planes is not None else None
         elif use_gi8:                                                      # (:87-91, solver.py:282-314)
             A0, B0 = ops.gram_i8(xidx, att_cls, yn, geom, has_b, self.alpha_act.data, self.qlvl_act)
         else:
@@ -405,6 +413,9 @@ class EfficientQConvHIP(PTQConv):
         if _os.environ.get("EFFQ_FP_TRAJ_STATS") and getattr(run, "fp_pred", None) is not None:     # diagnostic
             print(f"[fp_traj] {getattr(self, 'name', '?')}: {ops.read_fp_pred(run.fp_pred)}", flush=True)
         a_w, w_iters, hist, best_h = info["alpha_w"], info["w_iters"], info["hist"], info["best"]
+        if info["err"] >= 1000:
+            raise RuntimeError(f'{self.name}: the unweighted Gram system is not the integer system effq_gram_loss_i8 '
+                               f'expects (flag {info["err"] // 1000})')
         if info["err"] != 0:                                               # layer_helper.py:62-64
             if info["err"] == 2:
                 raise RuntimeWarning(f'Exceed maximum iteration ({100 * self.qlvl_w}) for alpha optimization')

@@ -243,6 +243,28 @@ size_t effq_gram_loss_ws_bytes(int n);
 int effq_gram_loss(const double* Au, const double* Bu, const double* syy_dev, const float* G, const float* b, int c2, int n,
                    int has_bias, double* sqerr_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the same losses for a GROUP of iterates of a wide layer, the quadratic form on the i8 matrix cores (exact integers)
+ * sum_c w_c^T Aww w_c = s_w^2 s_a^2 <K, J^T J> with K = Aww / s_a^2 (integer: sums of products of level ids) and
+ * J = the int8 level numerators of the iterate (Gq ring of effq_admm_run, as for conv3d_calib_step_i8).
+ *   effq_gram_loss_i8_supported: c2 % 32 == 0, (n - has_bias) % 64 == 0, w_levels <= 64;
+ *   effq_gram_loss_i8_num_planes(kmax): balanced base-256 digit planes for entries up to kmax (<= (La-1)^2 * voxels), -1 if > 6;
+ *   effq_gram_loss_i8_prepare: planes [P][round_up(n - has_bias, 256)][n - has_bias] int8 from Au (effq_gram_accum_i8_unw),
+ *     once per layer; *err_flag_dev is set non-zero if Au is not the integer system it should be;
+ *   effq_gram_loss_i8: hist_out[j][0] = hist_out[j][1] = sum (out - y)^2 of iterate j = 0 .. count-1 (count <= 16):
+ *     Gq [count][c2][n - has_bias], b [count][c2] (NULL without bias), states[j].alpha = the iterate's weight scale;
+ *     out = f32(alpha_a) f32(alpha_w) / ((La-1)(Lw-1)) * (J . k) + b in exact arithmetic (the contract of
+ *     conv3d_calib_step_i8), evaluated in integers and fp64.  ws: effq_gram_loss_i8_ws_bytes(), zero-filled once. */
+int effq_gram_loss_i8_supported(int c2, int n, int has_bias, int w_levels);
+int effq_gram_loss_i8_num_planes(long long kmax);
+size_t effq_gram_loss_i8_planes_bytes(int n, int has_bias, int nplanes);
+int effq_gram_loss_i8_prepare(const double* Au, int n, int has_bias, const float* act_alpha_dev, int act_levels,
+                              int nplanes, int8_t* planes, int32_t* err_flag_dev, void* stream);
+size_t effq_gram_loss_i8_ws_bytes(void);
+int effq_gram_loss_i8(const int8_t* planes, int nplanes, const double* Au, const double* Bu, const double* syy_dev,
+                      const int8_t* Gq, const float* b, const effq_fp_state* states, const float* act_alpha_dev,
+                      int act_levels, int w_levels, int c2, int n, int has_bias, int count, double* hist_out, void* ws,
+                      size_t ws_bytes, void* stream);
+
 
 /* The voxel list of an attention mask, by three small kernels (distinct weights + counts, segment layout, scatter): the
  * class weights are the few integers quirk Q1 leaves (ptqer.py:161-165).  vox_list: V + 2048 int32, chunk_cls: V/128 + 16
@@ -388,15 +410,19 @@ typedef struct effq_admm_run_args {
   /* optional second side stream with its own inverse workspace: the later inverses alternate between the two side
    * streams (their serial pivot phases overlap); NULL: one side stream */
   void* stream_side2; void* inv_ws_side2; size_t inv_ws_side2_bytes;
-  /* 1 if effq_admm_run takes the trajectory weight projection (effq_fixed_point_traj) for a layer of nw weights at
- * w_levels levels - the caller then passes fp_pred (effq_fp_traj_pred_bytes(), zero-filled) and fp_traj_ws
- * (effq_fp_traj_ws_bytes(nw)); otherwise both may be NULL and nothing needs to be allocated. */
-int effq_admm_uses_traj(size_t nw, int w_levels);
-/* loss_kind 4: the loss of an iterate from the layer's unweighted Gram system (effq_gram_loss): Au [n][n], Bu [c2][n]
+  /* loss_kind 4: the loss of an iterate from the layer's unweighted Gram system (effq_gram_loss): Au [n][n], Bu [c2][n]
    * (effq_gram_accum_i8_unw), syy = one device double, sum y^2 over this rank's voxels; conv_ws = effq_gram_loss_ws_bytes(n)
    * zero-filled once.  NULL for the other kinds. */
   const double* loss_Au; const double* loss_Bu; const double* loss_syy;
+  /* loss_kind 5: the same from effq_gram_loss_i8, in the groups the loss stream picks the iterates up in: loss_Au / Bu / syy
+   * as above, loss_planes / loss_nplanes from effq_gram_loss_i8_prepare, Gq_ring and act_alpha_dev as for loss_kind 1;
+   * conv_ws = effq_gram_loss_i8_ws_bytes() zero-filled once. */
+  const int8_t* loss_planes; int32_t loss_nplanes;
 } effq_admm_run_args;
+/* 1 if effq_admm_run takes the trajectory weight projection (effq_fixed_point_traj) for a layer of nw weights at
+ * w_levels levels - the caller then passes fp_pred (effq_fp_traj_pred_bytes(), zero-filled) and fp_traj_ws
+ * (effq_fp_traj_ws_bytes(nw)); otherwise both may be NULL and nothing needs to be allocated. */
+int effq_admm_uses_traj(size_t nw, int w_levels);
 int effq_admm_num_inverses(double rho, double rho_max, int iters, int rho_period);
 int effq_admm_run(const effq_admm_run_args* a);
 /* best = the EARLIEST iterate with the smallest hist[i][0] ("if i == 0 or lossf < best", EfficientQConv.py:139-142):

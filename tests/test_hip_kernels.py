@@ -528,6 +528,79 @@ def test_loss_from_the_unweighted_gram_system_equals_the_conv_loss(ops, c1, c2, 
     assert ops.gram_loss(Au, Bu, syy, G, b).cpu().tolist() == got          # deterministic
 
 
+@pytest.mark.parametrize("c1,c2,sp,La,Lw,count,with_bias", [
+    (64, 64, (6, 5, 7), 4, 4, 5, True),            # nw = 1728: 6.75 row tiles of 256 (a partial one), 2 digit planes
+    (128, 128, (5, 4, 6), 4, 4, 8, True),          # the 128-channel geometry of the BraTS net, a full group
+    (64, 32, (9, 8, 10), 16, 16, 3, False),        # 16 / 16 levels, no bias, 3 planes
+    (128, 256, (4, 4, 4), 4, 8, 2, True)])
+def test_losses_of_a_group_of_iterates_on_the_i8_matrix_cores(ops, c1, c2, sp, La, Lw, count, with_bias):
+    """effq_gram_loss_i8 (the per-iteration losses of the 128- / 256-channel layers): the quadratic form g^T Au g of every
+    iterate of a group as an exact integer <K, J^T J> on the i8 matrix cores (K = the Gram system of the level ids in
+    balanced base-256 digit planes, J = the int8 level numerators of the iterate), bias and cross terms in fp64.  Against
+    the fp64 evaluation of the same integer model (the contract of conv3d_calib_step_i8: out = f32(alpha_a) f32(alpha_w)
+    / ((La-1)(Lw-1)) * (J . k) + b): <= 2e-8 (the fixed-point y inside Bu; the quadratic form itself is exact); against the exact-integer conv pass it replaces: <= 2e-6 (that kernel's
+    fp32 epilogue); bit-identical run to run; a stacked group equals the iterates one at a time."""
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(c1 + 3 * c2 + La + 7 * count)
+    N, k, pad = 2, 3, 1
+    x = torch.relu(torch.randn(N, *sp, c1, generator=gen))
+    geom = make_geom((N, c1, *sp), c2, k, 1, pad)
+    od, oh, ow = geom.out_dims()
+    a_act, _, st_a = ops.fit_scale(dev(x), La, 0.0, 1.0)
+    xq, _, xidx = ops.quant_dequant_f64path(dev(x), st_a, La, 0.0, 1.0, want_idx=True)
+    alpha_act = torch.tensor(a_act, dtype=torch.float32, device="cuda:0")
+    y = dev(torch.randn(N, od, oh, ow, c2, generator=gen))
+    cls = ops.att_classes(dev(torch.randint(1, 4, (N, od, oh, ow), generator=gen).float()))
+    n = c1 * 27 + int(with_bias)
+    assert ops.gram_loss_i8_supported(c2, n, with_bias, Lw)
+    A0, B0, Au, Bu = ops.gram_i8(xidx, cls, y, geom, with_bias, alpha_act, La, unweighted=True)
+    V = N * od * oh * ow
+    planes = ops.gram_loss_i8_planes(Au, with_bias, alpha_act, La, V)
+    torch.cuda.synchronize()
+    assert int(planes._effq_err.item()) == 0
+    # the planes ARE the integer system: K = sum_p 256^p D_p = sum_v k k^T
+    nw = c1 * 27
+    X = O.patch_matrix(xidx.cpu().permute(0, 4, 1, 2, 3).float().numpy(), (k, k, k), 1, pad).astype(np.int64)
+    K = X @ X.T
+    Kp = sum((256 ** q) * planes[q, :nw].cpu().numpy().astype(np.int64) for q in range(planes.shape[0]))
+    assert np.array_equal(Kp, K) and not planes[:, nw:].any()
+    # `count` iterates: projected weights of perturbed solutions, stacked like the rings of effq_admm_run
+    Gq = torch.empty(count, c2, nw, dtype=torch.int8, device="cuda:0")
+    G = torch.empty(count, c2, nw, device="cuda:0")
+    states = torch.zeros(count, 5, dtype=torch.float64, device="cuda:0")
+    b = dev(torch.randn(count, c2, generator=gen) * 0.1) if with_bias else None
+    for j in range(count):
+        wst = dev(torch.randn(c2, nw, generator=gen) * (0.03 + 0.01 * j))
+        dual, v = torch.zeros_like(wst), torch.empty_like(wst)
+        ops.weight_fixed_point(wst, dual, v, Lw, states[j])
+        ops.admm_project_dual(v, wst, states[j], Lw, G[j], dual, 1.0, Gq[j])
+    syy = (y.double() ** 2).sum().reshape(1)
+    hist = ops.gram_loss_i8(planes, Au, Bu, syy, Gq, b, states, alpha_act, La, Lw)
+    got = hist.cpu().numpy()
+    assert np.array_equal(got[:, 0], got[:, 1])
+    xk = xidx.cpu().permute(0, 4, 1, 2, 3).double()
+    yd = y.cpu().permute(0, 4, 1, 2, 3).double()
+    sa = float(np.float32(a_act)) / (La - 1)
+    for j in range(count):
+        sw = float(np.float32(states[j, 0].item())) / (Lw - 1)
+        Jw = Gq[j].cpu().double().reshape(c2, c1, k, k, k)
+        out = torch.nn.functional.conv3d(xk, Jw, None, 1, pad) * (sa * sw)
+        if with_bias:
+            out = out + b[j].cpu().double().reshape(1, c2, 1, 1, 1)
+        ref = ((out - yd) ** 2).sum().item()
+        assert abs(got[j, 0] - ref) <= 2e-8 * ref, (j, got[j, 0], ref)       # (Bu carries y in 32-bit fixed point)
+        # the exact-integer conv pass it replaces (fp32 epilogue)
+        sq8 = torch.zeros(2, dtype=torch.float64, device="cuda:0")
+        if ops.conv_i8_supported(geom, La, Lw):
+            ops.conv_step_i8(xidx, Gq[j].reshape(c2, c1, k, k, k), None if b is None else b[j], geom, y, alpha_act, La,
+                             states[j], Lw, sq8)
+            assert abs(sq8.cpu().tolist()[0] - got[j, 0]) <= 2e-6 * ref, (j, sq8.cpu().tolist(), got[j, 0])
+        one = ops.gram_loss_i8(planes, Au, Bu, syy, Gq[j:j + 1], None if b is None else b[j:j + 1], states[j:j + 1],
+                               alpha_act, La, Lw).cpu().numpy()
+        assert one[0, 0] == got[j, 0], (j, one, got[j])
+    assert np.array_equal(ops.gram_loss_i8(planes, Au, Bu, syy, Gq, b, states, alpha_act, La, Lw).cpu().numpy(), got)
+
+
 @pytest.mark.parametrize("c1,c2,k,s,pad,sp,with_bias", [
     (4, 32, 3, 2, 1, (16, 14, 18), True),          # BraTS first conv (n = 109), ragged voxel count
     (32, 3, 1, 1, 0, (9, 7, 11), True),            # classifier (n = 33, c2 = 3)
