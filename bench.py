@@ -506,6 +506,15 @@ def main():
         if rccl_ranks != dist.get_world_size() or rccl_ranks != a.gpus:
             raise SystemExit(f"all-reduce over {backend} saw {rccl_ranks} ranks, expected {a.gpus}")
 
+    # EFFQ_DP_FORCE=1 on ONE rank: every data-parallel collective of the path is issued on RCCL (a 1-rank group: each
+    # all-reduce is the identity, but it costs what issuing it costs - the stream hop, the event records, the launch);
+    # the step-time difference to a plain run is the issue cost of the data-parallel path, measurable on one GPU
+    dp_forced = world == 1 and os.environ.get("EFFQ_DP_FORCE", "0") == "1"
+    if dp_forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+
     from efficientq_amd import calibrate as K, synth
     from efficientq_amd.hip_ops import get_ops
     args, model = build_model(a.levels, device, a.net)
@@ -536,12 +545,15 @@ def main():
         log(f"[rank {rank}] warmup {i}: {time.time() - t:.2f}s")
     unwrap = timer.wrap(ops)
     fence()
+    from efficientq_amd.qconv import SumReducer as _SR
+    _SR.calls = 0
     t0 = time.time()
     res = None
     for i in range(a.steps):
         res = one_step()
     fence()
     dt = time.time() - t0
+    coll_per_step = _SR.calls / max(1, a.steps)
     unwrap()
     timer.collect_library()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -603,6 +615,9 @@ def main():
         "stream_busy_frac": {k: round(v * 1e-3 / dt, 3) for k, v in busy.items()},
         # measured WITHOUT a profiler: HIP-event pairs on the main stream around every point where the chain waits for another
         # stream (the inverse of the next rho, the joins that end a layer), summed over the timed steps
+        "dp_forced": ({"collectives_per_step": coll_per_step, "rccl_direct": os.environ.get("EFFQ_RCCL_DIRECT", "1") != "0", "layers": 22 if a.net == "brats" else 28,
+                       "note": "EFFQ_DP_FORCE=1: one rank, every collective of the data-parallel path issued on RCCL"}
+                      if dp_forced else None),
         "main_queue_wait": {"ms_per_step": round(getattr(timer, "wait_ms", 0.0) / a.steps, 2),
                             "frac_of_step": round(getattr(timer, "wait_ms", 0.0) * 1e-3 / dt, 4)},
     }
@@ -654,6 +669,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
+    elif dp_forced:
         dist.destroy_process_group()
 
 

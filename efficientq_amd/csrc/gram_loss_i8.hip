@@ -37,20 +37,21 @@ struct Gl8Params {
   const int8_t* planes;      // [P][nwp][nw]
   const int8_t* Gq;          // [ncols][nw]: the int8 iterates of the group, stacked (ring slots are contiguous)
   unsigned long long* Qacc;  // [count]
-  int P, nwp, nw, ncols, c2, mt, nt;
+  unsigned int* ticket;      // next tile (zero before the launch; k_gl8_finish leaves it at zero again)
+  int P, nwp, nw, ncols, c2, mt, nt, ntiles;
 };
 
-__global__ __launch_bounds__(G8_T) void k_gl8(const Gl8Params p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char g8_smem[];
+// One tile of the product per call; the launch is a PERSISTENT grid of far fewer workgroups than CUs (EFFQ_GL8_WGS,
+// default 64) that draw tiles from a ticket: the losses only rank iterates that the chain has long left behind (a group of
+// 8 iterates has 1 - 3 ms of chain time to finish in), and a grid that fills the chip keeps the 256-row prox GEMM of the
+// chain (one workgroup per CU, 147 KB of LDS) waiting for CUs: 0.20 -> 0.42 ms per solve with 648 resident-at-will
+// workgroups.
+__device__ __forceinline__ void gl8_tile(const Gl8Params& p, int tile, unsigned char* g8_smem) {
   unsigned char* const As = g8_smem;                    // [2][G8_TILE]
   unsigned char* const Bs = g8_smem + 2 * G8_TILE;      // [2][G8_TILE]
-  // blocks b and b + 8 share an XCD (round-robin placement, speed only): the N tiles of one (row tile, plane) go to one
-  // XCD, so its L2 serves the plane panel to all of them
-  const int b = (int)blockIdx.x;
-  const int xcd = b & 7, s = b >> 3;
-  const int nti = s % p.nt, mp = (s / p.nt) * 8 + xcd;
-  if (mp >= p.mt * p.P) return;
-  const int mtile = mp / p.P, plane = mp % p.P;         // ascending row tile = descending work: the long ones first
+  // tiles in order of descending work (ascending row tile), the N tiles of one (row tile, plane) next to each other
+  const int nti = tile % p.nt, mp = tile / p.nt;
+  const int mtile = mp / p.P, plane = mp % p.P;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int lr = lane & 31, lh = lane >> 5;
@@ -178,6 +179,19 @@ __global__ __launch_bounds__(G8_T) void k_gl8(const Gl8Params p) {
   }
 }
 
+__global__ __launch_bounds__(G8_T) void k_gl8(const Gl8Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char g8_smem[];
+  __shared__ int s_tile;
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = (int)atomicAdd(p.ticket, 1u);
+    __syncthreads();
+    const int tile = s_tile;
+    if (tile >= p.ntiles) break;                         // (every workgroup draws exactly one ticket >= ntiles)
+    gl8_tile(p, tile, g8_smem);
+    __syncthreads();                                     // LDS and s_tile are reused
+  }
+}
+
 // K = rint(Au / s_a^2) on the weight rows, split into P balanced base-256 digits; rows nw .. nwp-1 of every plane are zero
 __global__ __launch_bounds__(256) void k_gl8_planes(const double* __restrict__ Au, int n, int nw, int nwp,
                                                     const float* __restrict__ alpha, int act_levels, int P,
@@ -212,6 +226,7 @@ struct Gl8Fin {
   const effq_fp_state* states;
   const float* alpha;
   unsigned long long* Qacc;
+  unsigned int* tile_ticket;  // k_gl8's ticket: reset here
   double* partials;           // [count][G8_FIN_WG]
   unsigned int* tickets;      // [count]
   double* hist;               // [count][2]
@@ -250,6 +265,7 @@ __global__ __launch_bounds__(256) void k_gl8_finish(const Gl8Fin p) {
     p.hist[2 * j] = loss;
     p.hist[2 * j + 1] = loss;
     __hip_atomic_store(p.Qacc + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left at zero for the next group
+    if (j == 0) __hip_atomic_store(p.tile_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -312,12 +328,17 @@ int effq_gram_loss_i8(const int8_t* planes, int nplanes, const double* Au, const
   char* base = reinterpret_cast<char*>(ws);                     // zero-filled once by the caller, left at zero by the kernels
   unsigned long long* Qacc = reinterpret_cast<unsigned long long*>(base);
   unsigned int* tickets = reinterpret_cast<unsigned int*>(base + sizeof(unsigned long long) * G8_MAXGROUP);
+  unsigned int* tile_ticket = tickets + G8_MAXGROUP;
   double* partials = reinterpret_cast<double*>(base + 256 + sizeof(unsigned long long) * G8_MAXGROUP);
   Gl8Params p;
   p.planes = planes; p.Gq = Gq; p.Qacc = Qacc;
   p.P = nplanes; p.nw = nw; p.nwp = g8_round_up(nw, G8_TM); p.ncols = count * c2; p.c2 = c2;
   p.mt = p.nwp / G8_TM; p.nt = (p.ncols + G8_TN - 1) / G8_TN;
-  const int groups = (p.mt * p.P + 7) / 8;
+  p.ntiles = p.mt * p.P * p.nt;
+  p.ticket = tile_ticket;
+  static const int wgs_env = getenv("EFFQ_GL8_WGS") ? atoi(getenv("EFFQ_GL8_WGS")) : 64;
+  int wgs = wgs_env < 1 ? 1 : wgs_env;
+  if (wgs > p.ntiles) wgs = p.ntiles;
   static bool attr_set = false;
   const int lds = 4 * G8_TILE;
   if (!attr_set) {
@@ -325,11 +346,11 @@ int effq_gram_loss_i8(const int8_t* planes, int nplanes, const double* Au, const
     attr_set = true;
   }
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(k_gl8, dim3((unsigned)(groups * 8 * p.nt)), dim3(G8_T), lds, st, p);
+  hipLaunchKernelGGL(k_gl8, dim3((unsigned)wgs), dim3(G8_T), lds, st, p);
   EFFQ_LAUNCH_CHECK();
   Gl8Fin f;
   f.Au = Au; f.Bu = Bu; f.syy = syy_dev; f.Gq = Gq; f.b = has_bias ? b : nullptr; f.states = states; f.alpha = act_alpha_dev;
-  f.Qacc = Qacc; f.partials = partials; f.tickets = tickets; f.hist = hist_out;
+  f.Qacc = Qacc; f.tile_ticket = tile_ticket; f.partials = partials; f.tickets = tickets; f.hist = hist_out;
   f.c2 = c2; f.n = n; f.nw = nw; f.has_bias = has_bias ? 1 : 0; f.act_levels = act_levels; f.w_levels = w_levels;
   hipLaunchKernelGGL(k_gl8_finish, dim3(G8_FIN_WG, count), dim3(256), 0, st, f);
   EFFQ_LAUNCH_CHECK();

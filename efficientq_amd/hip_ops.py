@@ -201,7 +201,7 @@ class HipOps:
         return float(host[0]), int(iters), int(done)
 
     def fit_scale(self, x: torch.Tensor, levels: int, lo: float, hi: float, reducer=None,
-                  guess_iters: int = 16, state: Optional[torch.Tensor] = None):
+                  guess_iters: int = 16, state: Optional[torch.Tensor] = None, abs_sums: Optional[torch.Tensor] = None):
         """project_by_iter on the device (layer_helper.py:40-70).
 
         ``reducer`` (callable on a device fp64 tensor, in place) sums statistics over data-parallel
@@ -213,9 +213,12 @@ class HipOps:
         n = x.numel()
         st = state if state is not None else self.new_fp_state()
         cap = 100 * levels
-        s0 = self.abs_sum(x)
-        if reducer is not None:
-            reducer(s0)
+        if abs_sums is not None:
+            s0 = abs_sums                      # [sum|x|, n], already summed over the data-parallel ranks by the caller
+        else:
+            s0 = self.abs_sum(x)
+            if reducer is not None:
+                reducer(s0)
         batch = max(4, int(guess_iters))
         if n >= FP_BRACKET_MIN and levels <= 256:
             return self._fit_scale_bracket(x, n, levels, lo, hi, reducer, batch, st, s0, cap)

@@ -41,6 +41,8 @@ def get_ops(device):
 class SumReducer:
     """Data-parallel SUM over calibration-volume shards (RCCL all-reduce; identity on one rank)."""
 
+    calls = 0          # collectives issued by this process (tests, bench)
+
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist = dist
@@ -48,10 +50,19 @@ class SumReducer:
         force = _os.environ.get("EFFQ_DP_FORCE", "0") == "1"
         self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.group = group
+        self.direct = None
+        if self.on and dist.get_backend(group) == "nccl":
+            # RCCL called through its C ABI on the stream the kernels run on (rccl.py): no hop to the process group's
+            # stream and back around every one of the ~50 tiny all-reduces of a layer.  EFFQ_RCCL_DIRECT=0: torch's path
+            from . import rccl
+            self.direct = rccl.get_comm(group)
 
     def __call__(self, t: torch.Tensor) -> torch.Tensor:
         if self.on:
-            if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            SumReducer.calls += 1
+            if t.is_cuda and self.direct is not None and t.is_contiguous():
+                self.direct.all_reduce_sum_(t)
+            elif t.is_cuda and self.dist.get_backend(self.group) == "gloo":
                 # rehearsal mode (several ranks on ONE GPU, where RCCL refuses duplicate devices):
                 # stage through the host; the product backend is "nccl" (= RCCL over xGMI)
                 h = t.cpu()
@@ -300,7 +311,6 @@ class EfficientQConvHIP(PTQConv):
         # the device idles for the round trip)
         my = ops.moments(yn)
         syy_local = my[1:2].clone()           # sum y^2 over THIS rank's voxels (the loss from the Gram system adds it)
-        my = red(my)
         mw = ops.moments(W0)
         att = None
         if self.lwq_verbose:
@@ -310,7 +320,18 @@ class EfficientQConvHIP(PTQConv):
                 if tuple(mask.shape[1:]) == tuple(self.output_fp.shape[2:]):
                     att = mask.to(dev).contiguous()
                     break
-        ma = red(ops.moments(att)) if att is not None else None
+        ma = ops.moments(att) if att is not None else None
+        # data-parallel: the layer's three statistics triples - targets, attention weights, sum|x| of the input for the
+        # start of its scale fit - travel as ONE message (they were three)
+        fit_here = bool(self.q_act and not self._act_inited)
+        sx = ops.abs_sum(xn) if (fit_here and red and hasattr(ops, "abs_sum")) else None
+        if red:
+            parts = [t for t in (my, ma, sx) if t is not None]
+            pack = red(torch.cat(parts))
+            off = 0
+            for t in parts:
+                t.copy_(pack[off:off + t.numel()])
+                off += t.numel()
         mh = torch.cat([my, mw] + ([ma] if ma is not None else [])).tolist()
         y_dim = mh[2]
         rho_scale = max(y_dim * self._std(mh[0:3]) / (W0.numel() * self._std(mh[3:6])), 1.0)
@@ -335,8 +356,9 @@ class EfficientQConvHIP(PTQConv):
             if self._act_inited:
                 xq = to_ndhwc(self._quantize_act(x))
             else:
+                kw_fit = dict(abs_sums=sx) if sx is not None else {}
                 a_act, act_iters, st = ops.fit_scale(xn, self.qlvl_act, 0.0, 1.0, reducer=red or None,
-                                                     guess_iters=12 * self.qlvl_act)
+                                                     guess_iters=12 * self.qlvl_act, **kw_fit)
                 self.alpha_act.data = torch.tensor(a_act, dtype=x.dtype, device=dev)
                 xq, _, xidx = ops.quant_dequant_f64path(xn, st, self.qlvl_act, 0.0, 1.0, want_idx=int_conv or use_gi8)
         else:

@@ -1,0 +1,119 @@
+"""All-reduce(SUM) on RCCL, enqueued DIRECTLY on the stream the kernels of the calibration run on.
+
+The data-parallel path issues ~50 tiny all-reduces per layer (statistics, the two sums of every iteration of the
+activation scale fit, the Gram system, the loss history), each BETWEEN two dependent kernels of one stream.
+``torch.distributed.all_reduce`` runs a collective on the process group's own stream: two event hops (current stream ->
+group stream -> current stream) around every call, each a barrier packet in the queue - measured on one MI355X with a
+1-rank RCCL group (``EFFQ_DP_FORCE=1``): +135 ms per calibration for 1115 collectives, 121 us each, 21 % of the step,
+before a single byte has crossed xGMI.  Here ``ncclAllReduce`` is called through the C ABI of the RCCL library the
+framework itself has loaded, with ``torch.cuda.current_stream()`` as its stream argument: the collective is one more
+kernel in the chain, ordered by the stream like every other.
+
+The communicator is created once per process group: rank 0 draws the ``ncclUniqueId`` and broadcasts its 128 bytes
+through ``torch.distributed`` (whatever backend the group has); ``ncclCommInitRank`` is collective.  Plumbing only:
+device memory, streams and the rendezvous stay the framework's.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+from typing import Optional
+
+import torch
+
+NCCL_UNIQUE_ID_BYTES = 128
+_DT = {torch.int8: 0, torch.uint8: 1, torch.int32: 2, torch.int64: 4, torch.float16: 6, torch.float32: 7,
+       torch.float64: 8, torch.bfloat16: 9}
+NCCL_SUM = 0
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_ubyte * NCCL_UNIQUE_ID_BYTES)]     # (c_char fields read back truncated at the first NUL)
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["/opt/rocm/lib/librccl.so"]
+    err = None
+    for path in cands:
+        try:
+            lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError as e:             # pragma: no cover
+            err = e
+            continue
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+        lib.ncclGetUniqueId.restype = C.c_int
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        lib.ncclCommInitRank.restype = C.c_int
+        lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclAllReduce.restype = C.c_int
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        lib.ncclCommDestroy.restype = C.c_int
+        lib.ncclGetErrorString.argtypes = [C.c_int]
+        lib.ncclGetErrorString.restype = C.c_char_p
+        _lib = lib
+        return lib
+    raise OSError(f"librccl.so not found ({err})")
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {_load().ncclGetErrorString(rc).decode(errors='replace')}")
+
+
+class DirectComm:
+    """One RCCL communicator over the ranks of a torch.distributed group, used for in-stream SUM all-reduces."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        lib = _load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        uid = _UniqueId()
+        if self.rank == 0:
+            _check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        box = [C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        C.memmove(C.byref(uid), box[0], NCCL_UNIQUE_ID_BYTES)
+        self.comm = C.c_void_p()
+        _check(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+        self.calls = 0
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError("DirectComm.all_reduce_sum_: contiguous device tensors only")
+        st = torch.cuda.current_stream(t.device).cuda_stream
+        _check(_load().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _DT[t.dtype], NCCL_SUM, self.comm,
+                                     C.c_void_p(st)), "ncclAllReduce")
+        self.calls += 1
+        return t
+
+    def close(self):
+        if self.comm:
+            _load().ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
+
+
+_comms = {}
+
+
+def get_comm(group=None) -> Optional[DirectComm]:
+    """The communicator of `group` (created collectively on first use), or None when EFFQ_RCCL_DIRECT=0."""
+    if os.environ.get("EFFQ_RCCL_DIRECT", "1") == "0":
+        return None
+    key = id(group) if group is not None else 0
+    if key not in _comms:
+        _comms[key] = DirectComm(group)
+    return _comms[key]
+
+
+def close_all():
+    for c in _comms.values():
+        c.close()
+    _comms.clear()

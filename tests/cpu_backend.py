@@ -46,12 +46,15 @@ class OracleOps:
     def new_fp_state(self):
         return torch.zeros(5, dtype=torch.float64)
 
-    def fit_scale(self, x, levels, lo, hi, reducer=None, guess_iters=16, state=None):
+    def fit_scale(self, x, levels, lo, hi, reducer=None, guess_iters=16, state=None, abs_sums=None):
         st = state if state is not None else self.new_fp_state()
         xd = x.double()
-        s0 = self.abs_sum(x)
-        if reducer is not None:
-            reducer(s0)
+        if abs_sums is not None:
+            s0 = abs_sums
+        else:
+            s0 = self.abs_sum(x)
+            if reducer is not None:
+                reducer(s0)
         a, a_old, n, cap = (s0[0] / s0[1]).item(), -999.0, 0, 100 * levels
         while abs(a - a_old) > 1e-5 and n < cap:
             b = O.discretize(xd / a, levels, lo, hi)

@@ -35,21 +35,24 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
     assert dist.get_backend() == "nccl"
-    calls = {"n": 0}
-    real = dist.all_reduce
-
-    def counted(*a, **kw):
-        calls["n"] += 1
-        return real(*a, **kw)
-    dist.all_reduce = counted
+    from efficientq_amd.qconv import SumReducer
+    from efficientq_amd import rccl
     os.environ["EFFQ_DP_FORCE"] = "1"
-    forced = run(vols)
-    forced["collectives"] = calls["n"]
+    SumReducer.calls = 0
+    forced = run(vols)                                  # RCCL called directly on the kernels' stream (rccl.py)
+    forced["collectives"] = SumReducer.calls
+    comm = rccl.get_comm(None)
+    forced["direct_calls"] = comm.calls if comm is not None else -1
+    os.environ["EFFQ_RCCL_DIRECT"] = "0"
+    SumReducer.calls = 0
+    via_torch = run(vols)                               # the same collectives through torch.distributed
+    via_torch["collectives"] = SumReducer.calls
+    os.environ["EFFQ_RCCL_DIRECT"] = "1"
     os.environ["EFFQ_DP_FORCE"] = "0"
     plain = run(vols)
-    dist.all_reduce = real
+    rccl.close_all()
     dist.destroy_process_group()
-    torch.save(dict(forced=forced, plain=plain), out)
+    torch.save(dict(forced=forced, via_torch=via_torch, plain=plain), out)
 
 
 if __name__ == "__main__":
