@@ -493,16 +493,25 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     rccl_ranks = 1
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-            probe = torch.ones(1, device=device)
+            # the process group is the rendezvous; the collectives of the calibration (and the ones below) are RCCL calls
+            # on the kernels' own stream (efficientq_amd/rccl.py).  No device_id: an eagerly created framework communicator
+            # brings HIP streams of its own, which alias the calibration's streams onto shared hardware queues (+20 % per
+            # calibration, measured on one GPU with a 1-rank group that was never used)
+            dist.init_process_group("nccl")
+            from efficientq_amd import rccl as _rccl
+            comm = _rccl.get_comm(None)
+        if comm is not None:
+            rccl_ranks = comm.barrier(device)        # an actual all-reduce over RCCL: the rank count it reports
         else:
-            dist.init_process_group(backend)
-            probe = torch.ones(1)
-        dist.all_reduce(probe)                       # an actual all-reduce over the backend: the rank count it reports
-        rccl_ranks = int(probe.item())
+            if not dist.is_initialized():
+                dist.init_process_group(backend)
+            probe = torch.ones(1, device=device) if backend == "nccl" else torch.ones(1)
+            dist.all_reduce(probe)
+            rccl_ranks = int(probe.item())
         if rccl_ranks != dist.get_world_size() or rccl_ranks != a.gpus:
             raise SystemExit(f"all-reduce over {backend} saw {rccl_ranks} ranks, expected {a.gpus}")
 
@@ -513,7 +522,7 @@ def main():
     if dp_forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29655")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        dist.init_process_group("nccl", rank=0, world_size=1)
 
     from efficientq_amd import calibrate as K, synth
     from efficientq_amd.hip_ops import get_ops
@@ -534,7 +543,9 @@ def main():
         return K.calibrate_model(model, vols, a.net, args.init_stride)
 
     def fence():
-        if world > 1:
+        if world > 1 and comm is not None:
+            comm.barrier(device)
+        elif world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -557,7 +568,9 @@ def main():
     unwrap()
     timer.collect_library()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-    if world > 1:
+    if world > 1 and comm is not None:
+        comm.all_reduce_max_(tmax)
+    elif world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     total_vols = a.vols * world * a.steps
@@ -667,10 +680,13 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    elif dp_forced:
+    if world > 1 or dp_forced:
+        if comm is not None:
+            comm.barrier(device)
+        elif world > 1:
+            dist.barrier()
+        from efficientq_amd import rccl as _rccl
+        _rccl.close_all()
         dist.destroy_process_group()
 
 

@@ -141,6 +141,10 @@ SIGNATURES = {
     "effq_pack_levels": (_I, [_P, _SZ, _I, _P, _P]),
     "effq_unpack_levels": (_I, [_P, _SZ, _I, _P, _P]),
     "effq_ainv_ld": (_I, [_I]),
+    "effq_fp_bracket_export_words": (_SZ, []),
+    "effq_fp_bracket_export": (_I, [_P, _SZ, _P, _P, _SZ, _P]),
+    "effq_fp_bracket_rebase": (_I, [_P, _P, _SZ, _P]),
+    "effq_fp_bracket_import": (_I, [_P, _SZ, _P, _I, _SZ, _P, _P, _SZ, _P]),
     "effq_admm_uses_traj": (_I, [_SZ, _I]),
     "effq_gram_loss_i8_supported": (_I, [_I, _I, _I, _I]),
     "effq_gram_loss_i8_num_planes": (_I, [C.c_longlong]),

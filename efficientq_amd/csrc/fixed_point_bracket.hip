@@ -60,6 +60,11 @@ struct FbrHdr {
   long long widen;              // doublings of the safety factor: escapes from brackets that WERE such predictions
   long long base;               // FBR_X, or FBR_Z once the first pass has listed the non-zeros
   long long z_total;            // length of the base list
+  // ---- a fit that was IMPORTED (data-parallel ranks: effq_fp_bracket_import): its base is the gathered list of the values
+  // that were undecided under [guard_lo, guard_hi] and DZ holds the tallies of everything decided under that bracket, so
+  // the fit is only valid while the iterates stay inside it: an iterate outside ends it with state.done = 4
+  double guard_lo, guard_hi;    // (0, inf) for an ordinary fit
+  long long ext[4];             // tallies of everything the OTHER ranks and this one had decided before the exchange (0)
 };
 static_assert(sizeof(FbrHdr) <= 256, "FbrHdr layout");
 
@@ -273,8 +278,8 @@ __device__ void fbr_plan(FbrHdr* h, double a_new, double alpha, double a_pp, int
   const bool base_z = h->base == FBR_Z;
   if (h->src != FBR_X && !(a_new >= h->blo && a_new <= h->bhi)) {     // the iterate left the bracket (or is NaN)
     h->src = h->base;
-    h->blo = base_z ? 1e-300 : 0.0;
-    h->bhi = base_z ? 1e300 : INFINITY;
+    h->blo = fmax(base_z ? 1e-300 : 0.0, h->guard_lo);
+    h->bhi = fmin(base_z ? 1e300 : INFINITY, h->guard_hi);
     h->list_total = base_z ? h->z_total : 0;
     h->escapes += 1;
     // a far end set by a horizon or by an older bracket says nothing about the prediction of the limit; only an escape
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(FBR_FT) void k_fbr_finish(FbrWs w, effq_fp_state* s
       long long t[5];
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
-        t[s] = 0;
+        t[s] = (s < 4) ? h->ext[s] : 0;
         for (int wv = 0; wv < FBR_FT / 64; ++wv) t[s] += s_red[s][wv];
       }
       const double q = h->q;
@@ -410,6 +415,8 @@ __global__ __launch_bounds__(FBR_FT) void k_fbr_finish(FbrWs w, effq_fp_state* s
       done = 2;
     else if (!(fabs(a_new - alpha) > tol))
       done = 1;
+    else if (!(a_new >= h->guard_lo && a_new <= h->guard_hi))
+      done = 4;                                  // left the bracket an imported fit is valid under: the caller falls back
     st->done = done;
     if (done == 0) fbr_plan(h, a_new, alpha, a_pp, it, n);
   }
@@ -467,6 +474,142 @@ __global__ __launch_bounds__(FBR_T) void k_fbr_init(FbrWs w, effq_fp_state* st, 
   h->widen = 0;
   h->base = FBR_X;
   h->z_total = 0;
+  h->guard_lo = 0.0;
+  h->guard_hi = INFINITY;
+  for (int i = 0; i < 4; ++i) h->ext[i] = 0;
+}
+
+// ---- data-parallel ranks: gather once, finish everywhere -------------------------------------------------------------
+// A fit over volumes sharded across ranks needs the two sums of EVERY iteration all-reduced: ~40 collectives per layer at
+// 4 levels, each between two dependent kernels.  But once the bracket [blo, bhi] is narrow, all that is left of a rank's
+// shard is (a) four integers - the tallies of the values decided under the bracket - and (b) the short list of the
+// undecided ones.  effq_fp_bracket_export hands both out; the caller all-reduces (a), all-gathers (b), and
+// effq_fp_bracket_import sets up a fit over the gathered list with the summed tallies as its constant part, which every
+// rank then runs to the end ON ITS OWN - same integers, same order, same kernels: bit-identical iterates on every rank, no
+// further collective.  The imported fit is valid while its iterates stay inside [blo, bhi] (state.done = 4 otherwise).
+// out: [0..3] tallies, [4] list length (-1: no list yet, -2: horizon bracket, see below), [5], [6] bit patterns of the
+// bracket, [8 .. 8 + G] prefix offsets of the list segments (scratch for k_fbr_export_copy)
+__global__ __launch_bounds__(FBR_FT) void k_fbr_export(FbrWs w, long long* __restrict__ out) {
+  __shared__ long long s_red[4][FBR_FT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const FbrHdr h = *w.hdr;
+  const int G = (int)h.G;
+  long long a[4] = {0, 0, 0, 0};
+  for (int g = tid; g < G; g += FBR_FT)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] += w.DZ[g * 4 + s] + w.D[g * 4 + s];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    a[s] = wave_sum_i64(a[s]);
+    if (lane == 0) s_red[s][wid] = a[s];
+  }
+  __syncthreads();
+  if (tid < 4) {
+    long long t = h.ext[tid];
+    for (int wv = 0; wv < FBR_FT / 64; ++wv) t += s_red[tid][wv];
+    out[tid] = t;
+  }
+  if (tid == 0) {
+    long long run = 0;
+    for (int g = 0; g < G; ++g) {
+      out[8 + g] = run;
+      run += (h.src == FBR_X) ? 0 : (long long)w.segcnt[(h.src - 1) * FBR_MAXG + g];
+    }
+    out[8 + G] = run;
+    // -1: no list yet; -2: the list belongs to a HORIZON bracket (many levels: it only reaches as far as the next few
+    // iterations are expected to get, and the iterates leave it by design): not worth exchanging
+    out[4] = (h.src == FBR_X) ? -1 : ((h.planned != 0) ? -2 : run);
+    out[5] = __double_as_longlong(h.blo);      // the bracket these tallies and this list are valid under: ranks plan on
+    out[6] = __double_as_longlong(h.bhi);      // their own shard's density, so their brackets may differ
+  }
+}
+
+// workgroup g copies segment g of the list behind the segments before it; everything beyond the list - or the whole
+// buffer if there is no list to hand out or it does not fit - is zero-filled (zeros are harmless to the receiver)
+__global__ __launch_bounds__(FBR_T) void k_fbr_export_copy(FbrWs w, const long long* __restrict__ out,
+                                                          float* __restrict__ list_out, size_t cap) {
+  const FbrHdr h = *w.hdr;
+  const int G = (int)h.G, g = blockIdx.x, tid = threadIdx.x;
+  const long long count = out[4];
+  const bool ok = count >= 0 && (size_t)count <= cap;
+  const size_t used = ok ? (size_t)count : 0;
+  if (ok && h.src != FBR_X) {
+    const float* L = w.L[h.src - 1] + (size_t)g * (size_t)h.per;
+    const size_t o = (size_t)out[8 + g], c = (size_t)(out[8 + g + 1] - out[8 + g]);
+    for (size_t i = tid; i < c; i += FBR_T) list_out[o + i] = L[i];
+  }
+  const size_t tail = cap - used, per = (tail + G - 1) / G;
+  const size_t z0 = used + (size_t)g * per, z1 = (z0 + per < cap) ? z0 + per : cap;
+  for (size_t i = z0 + tid; i < z1; i += FBR_T) list_out[i] = 0.0f;
+}
+
+// back from an imported fit that left its bracket: the rank's own list and tallies belong to a bracket the iterates have
+// moved on from since - the next pass starts from the base, exactly as after an escape
+__global__ void k_fbr_rebase(FbrWs w, effq_fp_state* st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  FbrHdr* h = w.hdr;
+  const bool base_z = h->base == FBR_Z;
+  h->src = h->base;
+  h->blo = fmax(base_z ? 1e-300 : 0.0, h->guard_lo);
+  h->bhi = fmin(base_z ? 1e300 : INFINITY, h->guard_hi);
+  h->list_total = base_z ? h->z_total : 0;
+  h->narrow = 0;
+  h->planned = 0;
+  h->r_prev = 0.0;
+  h->mono = 0;
+  if (st->done == 4) st->done = 0;
+}
+
+// pack (all-reduced over the ranks): [0..3] summed tallies, then per rank {list length, bits of blo, bits of bhi}.
+// Decided ON THE DEVICE (the host has not seen the lengths): the exchange is usable if every rank handed out a list that
+// fitted its slot and the current iterate lies inside the intersection of the ranks' brackets; otherwise state.done = 4 and
+// the launches of the imported fit that follow are no-ops.
+__global__ __launch_bounds__(FBR_T) void k_fbr_import(FbrWs dst, const FbrHdr* __restrict__ src_hdr,
+                                                      const long long* __restrict__ pack, int world, long long cap,
+                                                      long long G, long long per, effq_fp_state* st) {
+  for (int i = threadIdx.x; i < 4 * FBR_MAXG; i += FBR_T) {
+    dst.DZ[i] = 0;
+    dst.D[i] = 0;
+    dst.U[i] = 0;
+  }
+  if (threadIdx.x != 0) return;
+  double glo = 0.0, ghi = INFINITY;
+  bool ok = st->done == 0;
+  for (int r = 0; r < world; ++r) {
+    const long long len = pack[4 + 3 * r];
+    if (len < 0 || len > cap) ok = false;
+    glo = fmax(glo, __longlong_as_double(pack[5 + 3 * r]));
+    ghi = fmin(ghi, __longlong_as_double(pack[6 + 3 * r]));
+  }
+  if (!(glo <= st->alpha && st->alpha <= ghi)) ok = false;
+  FbrHdr h = *src_hdr;              // iterates and integer unit: carried over (the same on every rank)
+  // valid under the INTERSECTION of the ranks' brackets; the planning state starts afresh, so that every rank plans alike
+  // from here (it only ever decides what is worth doing - the iterates do not depend on it)
+  h.guard_lo = glo;
+  h.guard_hi = ghi;
+  h.blo = glo;
+  h.bhi = ghi;
+  for (int i = 0; i < 4; ++i) h.ext[i] = pack[i];
+  h.r_prev = 0.0;
+  h.density = 0.0;
+  h.mono = 0;
+  h.planned = 0;
+  h.widen = 0;
+  h.escapes = 0;
+  h.narrowings = 0;
+  h.visited = 0;
+  h.src = FBR_X;                    // the gathered lists ARE this fit's tensor; its first pass drops their zero padding
+  h.dst = FBR_Z;                    // (and whatever the narrower common bracket decides) into the base list
+  h.narrow = 1;
+  h.nlo = fmax(glo, 1e-300);
+  h.nhi = fmin(ghi, 1e300);
+  h.base = FBR_X;
+  h.z_total = 0;
+  h.list_total = 0;
+  h.G = G;
+  h.per = per;
+  *dst.hdr = h;
+  if (!ok && st->done == 0) st->done = 4;
 }
 
 }  // namespace effq
@@ -522,6 +665,43 @@ int effq_fp_bracket_stats(const float* x, size_t n, int levels, double lo, doubl
   hipStream_t s = as_stream(stream);
   fbr_launch_iter(x, n, w, state_dev, lo, hi, d, s);
   hipLaunchKernelGGL(k_fbr_finish, dim3(1), dim3(FBR_FT), 0, s, w, state_dev, n, lo, d, 0.0, 1, 1);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+size_t effq_fp_bracket_export_words(void) { return 8 + FBR_MAXG + 1; }
+
+int effq_fp_bracket_export(const void* ws, size_t n, long long* out, float* list_out, size_t list_cap, void* stream) {
+  EFFQ_CHECK_ARG(ws && out && list_out && n > 0 && list_cap > 0);
+  size_t G, per;
+  fbr_shape(n, &G, &per);
+  const FbrWs w = fbr_carve(const_cast<void*>(ws), n);
+  hipLaunchKernelGGL(k_fbr_export, dim3(1), dim3(FBR_FT), 0, as_stream(stream), w, out);
+  hipLaunchKernelGGL(k_fbr_export_copy, dim3((unsigned)G), dim3(FBR_T), 0, as_stream(stream), w, out, list_out, list_cap);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_fp_bracket_import(const void* ws_src, size_t n_src, const long long* pack_dev, int world, size_t list_cap,
+                           effq_fp_state* state_dev, void* ws_dst, size_t ws_dst_bytes, void* stream) {
+  EFFQ_CHECK_ARG(ws_src && pack_dev && state_dev && ws_dst && n_src > 0 && world > 0 && list_cap > 0 && ws_src != ws_dst);
+  const size_t m = (size_t)world * list_cap;
+  if (ws_dst_bytes < fbr_ws_bytes(m)) {
+    set_error("fp_bracket_import: workspace %zu < %zu bytes", ws_dst_bytes, fbr_ws_bytes(m));
+    return EFFQ_ERR_WORKSPACE;
+  }
+  size_t G, per;
+  fbr_shape(m, &G, &per);
+  hipLaunchKernelGGL(k_fbr_import, dim3(1), dim3(FBR_T), 0, as_stream(stream), fbr_carve(ws_dst, m),
+                     fbr_carve(const_cast<void*>(ws_src), n_src).hdr, pack_dev, world, (long long)list_cap, (long long)G,
+                     (long long)per, state_dev);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+int effq_fp_bracket_rebase(effq_fp_state* state_dev, void* ws, size_t n, void* stream) {
+  EFFQ_CHECK_ARG(state_dev && ws && n > 0);
+  hipLaunchKernelGGL(k_fbr_rebase, dim3(1), dim3(64), 0, as_stream(stream), fbr_carve(ws, n), state_dev);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

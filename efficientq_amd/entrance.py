@@ -71,7 +71,9 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        # (no device_id: the group is the rendezvous only; the collectives are RCCL calls on the kernels' stream, rccl.py -
+        # an eagerly created framework communicator brings streams of its own that slow the calibration by 20 %)
+        dist.init_process_group('nccl')
         args.device = local
     QConv, Qinfo, kwQ = Cf.get_conv_class(args)
     cube, info = Cf.get_model_cube(args, QConv, kwQ)

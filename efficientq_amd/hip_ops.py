@@ -19,6 +19,12 @@ ADMM_TOL = 1e-5   # layer_helper.py:55
 import os as _os
 FP_BRACKET_MIN = int(_os.environ.get("EFFQ_FP_BRACKET_MIN", 1 << 18))
 COOP_FIXED_POINT = _os.environ.get("EFFQ_COOP_FP", "1") != "0"
+# data-parallel activation fit: after DP_GATHER_AFTER all-reduced iterations the ranks exchange their tallies and undecided
+# lists once and finish on their own (effq_fp_bracket_export / _import); lists longer than DP_GATHER_MAX_BYTES in all: more
+# all-reduced iterations first.  EFFQ_DP_GATHER_FIT=0: one all-reduce per iteration (A/B)
+DP_GATHER_FIT = _os.environ.get("EFFQ_DP_GATHER_FIT", "1") != "0"
+DP_GATHER_AFTER = int(_os.environ.get("EFFQ_DP_GATHER_AFTER", "4"))
+DP_GATHER_MAX_BYTES = int(_os.environ.get("EFFQ_DP_GATHER_MAX_BYTES", str(128 << 20)))
 BUCKET_FIXED_POINT = _os.environ.get("EFFQ_BUCKET_FP", "1") != "0"
 TRAJ_FIXED_POINT = _os.environ.get("EFFQ_FP_TRAJ", "1") != "0"
 SIDE2_STREAM = _os.environ.get("EFFQ_SIDE2", "1") != "0"
@@ -250,24 +256,76 @@ class HipOps:
         # unsigned quantiser = post-ReLU input: the first pass already drops the exact zeros
         check(self.lib.effq_fp_bracket_init(_ptr(st), _ptr(s0), n, levels, int(lo == 0.0), _ptr(ws), ws.numel(),
                                             self.stream), "effq_fp_bracket_init")
+        gather = (reducer is not None and DP_GATHER_FIT and lo == 0.0 and hasattr(reducer, "all_gather"))
+        dp_iters = DP_GATHER_AFTER
         while True:
             if reducer is None:
                 check(self.lib.effq_fp_bracket_run(_ptr(x), n, levels, lo, hi, ADMM_TOL, cap, batch, _ptr(st), _ptr(ws),
                                                    self.stream), "effq_fp_bracket_run")
             else:
                 sums = st[2:4]
-                for _ in range(batch):
+                for _ in range(dp_iters if gather else batch):
                     check(self.lib.effq_fp_bracket_stats(_ptr(x), n, levels, lo, hi, _ptr(st), _ptr(ws), self.stream),
                           "effq_fp_bracket_stats")
                     reducer(sums)
                     check(self.lib.effq_fp_bracket_update(n, levels, lo, hi, ADMM_TOL, cap, _ptr(st), _ptr(ws),
                                                           self.stream), "effq_fp_bracket_update")
+                if gather:
+                    r = self._fit_scale_gathered(x, n, levels, lo, hi, reducer, st, ws, cap)
+                    if not isinstance(r, int):
+                        return r
+                    dp_iters = r                   # not usable yet (or the gathered fit left its bracket): more all-reduced
+                    continue                       # iterations first
             alpha, iters, done = self.read_fp_state(st)   # one host sync per batch
             if done == 1:
                 return alpha, iters, st
             if done == 2:
                 raise RuntimeWarning(f"Exceed maximum iteration ({cap}) for alpha optimization")
             batch = min(max(8, iters // 2), 256)
+
+    def _fit_scale_gathered(self, x, n, levels, lo, hi, reducer, st, ws, cap):
+        """Data-parallel ranks, "gather once" (effq_fp_bracket_export / _import): what is left of every rank's shard under
+        the current bracket - four integer tallies and the list of the undecided values - is exchanged with TWO collectives
+        (tallies + list lengths + brackets in one all-reduce, the zero-padded lists in one all-gather of a fixed size), and
+        every rank finishes the fit on its own, bit-identically.  No host round trip on the way: whether the exchange was
+        usable is decided on the device.  Returns (alpha, iters, state), or - when the fit must go on with all-reduced
+        iterations: no list yet / lists too long / horizon bracket / an iterate left the bracket of the import - the number of
+        such iterations to run before the next attempt."""
+        world, rank = reducer.world, reducer.rank
+        dev = self.device
+        slot = max(4096, min((n + 3) // 4 * 4, DP_GATHER_MAX_BYTES // 4 // max(1, world)))      # floats per rank
+        lst = self._workspace("fp_gather_list", 4 * slot).view(torch.float32)
+        exp = torch.empty(self.lib.effq_fp_bracket_export_words(), dtype=torch.int64, device=dev)
+        check(self.lib.effq_fp_bracket_export(_ptr(ws), n, _ptr(exp), _ptr(lst), slot, self.stream),
+              "effq_fp_bracket_export")
+        # one int64 message: [0..3] tallies (summed), then one slot triple per rank - list length, bit patterns of the
+        # bracket its tallies are valid under (the other ranks add zeros)
+        pack = torch.zeros(4 + 3 * world, dtype=torch.int64, device=dev)
+        pack[:4] = exp[:4]
+        pack[4 + 3 * rank: 7 + 3 * rank] = exp[4:7]
+        reducer(pack)
+        gathered = reducer.all_gather(lst[:slot])               # second (and last) message of the fit
+        m = world * slot
+        ws2 = self._workspace("fp_bracket_gathered", self.lib.effq_fp_bracket_ws_bytes(m))
+        check(self.lib.effq_fp_bracket_import(_ptr(ws), n, _ptr(pack), world, slot, _ptr(st), _ptr(ws2), ws2.numel(),
+                                              self.stream), "effq_fp_bracket_import")
+        batch = 12 * levels
+        while True:
+            check(self.lib.effq_fp_bracket_run(_ptr(gathered), m, levels, lo, hi, ADMM_TOL, cap, batch, _ptr(st), _ptr(ws2),
+                                               self.stream), "effq_fp_bracket_run")
+            alpha, iters, done = self.read_fp_state(st)         # the fit's one host read (in the common case)
+            if done == 1:
+                return alpha, iters, st
+            if done == 2:
+                raise RuntimeWarning(f"Exceed maximum iteration ({cap}) for alpha optimization")
+            if done == 4:                                       # exchange not usable / left the bracket of the import:
+                check(self.lib.effq_fp_bracket_rebase(_ptr(st), _ptr(ws), n, self.stream), "effq_fp_bracket_rebase")
+                # on with all-reduced iterations, from the base - as many as the lists need to shrink into their slots (the
+                # undecided share falls by ~0.57 every two iterations at few levels: profiles/r03_fp_bracket_trace_*)
+                lens = pack[4::3].cpu().tolist()
+                worst = max(lens) if min(lens) >= 0 else 0
+                return DP_GATHER_AFTER if worst <= slot else max(2, min(32, int(math.ceil(3.6 * math.log(worst / slot))) + 1))
+            batch = min(2 * batch, 256)
 
     def fp_bracket_diagnostics(self):
         """The header of the bracketed fixed point's workspace after a fit (tests, tuning)."""

@@ -72,6 +72,31 @@ class SumReducer:
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """Rank-major concatenation of every rank's `t` (same length on every rank)."""
+        if not self.on:
+            return t
+        SumReducer.calls += 1
+        if t.is_cuda and self.direct is not None and t.is_contiguous():
+            return self.direct.all_gather(t)
+        world = self.dist.get_world_size(self.group)
+        if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            h = t.cpu()
+            parts = [torch.empty_like(h) for _ in range(world)]
+            self.dist.all_gather(parts, h, group=self.group)
+            return torch.cat(parts).to(t.device)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        self.dist.all_gather(parts, t.contiguous(), group=self.group)
+        return torch.cat(parts)
+
+    @property
+    def world(self) -> int:
+        return self.dist.get_world_size(self.group) if self.on else 1
+
+    @property
+    def rank(self) -> int:
+        return self.dist.get_rank(self.group) if self.on else 0
+
     def __bool__(self):
         return self.on
 

@@ -33,6 +33,8 @@ class _UniqueId(C.Structure):
 
 
 _lib = None
+_uid_seq = 0
+NCCL_MAX = 2
 
 
 def _load():
@@ -53,6 +55,8 @@ def _load():
         lib.ncclCommInitRank.restype = C.c_int
         lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.ncclAllReduce.restype = C.c_int
+        lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclAllGather.restype = C.c_int
         lib.ncclCommDestroy.argtypes = [C.c_void_p]
         lib.ncclCommDestroy.restype = C.c_int
         lib.ncclGetErrorString.argtypes = [C.c_int]
@@ -77,22 +81,57 @@ class DirectComm:
         uid = _UniqueId()
         if self.rank == 0:
             _check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else None]
+        raw = C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else None
         if self.world > 1:
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        C.memmove(C.byref(uid), box[0], NCCL_UNIQUE_ID_BYTES)
+            if group is None:
+                # through the rendezvous store (plain TCP): the framework's own NCCL communicator - and the extra HIP
+                # streams it brings, which alias the calibration's streams onto shared hardware queues (measured: +20 % per
+                # calibration with an eagerly initialised "nccl" group that is never used) - is never created
+                global _uid_seq
+                store = dist.distributed_c10d._get_default_store()
+                key = f"effq_rccl_uid_{_uid_seq}"
+                _uid_seq += 1
+                if self.rank == 0:
+                    store.set(key, raw)
+                raw = store.get(key)
+            else:
+                box = [raw]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group)
+                raw = box[0]
+        C.memmove(C.byref(uid), bytes(raw), NCCL_UNIQUE_ID_BYTES)
         self.comm = C.c_void_p()
         _check(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
         self.calls = 0
 
-    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+    def all_reduce_sum_(self, t: torch.Tensor, op: int = NCCL_SUM) -> torch.Tensor:
         if not (t.is_cuda and t.is_contiguous()):
             raise ValueError("DirectComm.all_reduce_sum_: contiguous device tensors only")
         st = torch.cuda.current_stream(t.device).cuda_stream
-        _check(_load().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _DT[t.dtype], NCCL_SUM, self.comm,
+        _check(_load().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _DT[t.dtype], op, self.comm,
                                      C.c_void_p(st)), "ncclAllReduce")
         self.calls += 1
         return t
+
+    def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
+        return self.all_reduce_sum_(t, NCCL_MAX)
+
+    def barrier(self, device) -> int:
+        """Every rank has reached this point and the device has drained; returns the number of ranks that took part."""
+        one = torch.ones(1, dtype=torch.float32, device=device)
+        self.all_reduce_sum_(one)
+        torch.cuda.synchronize(device)
+        return int(one.item())
+
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """rank-major concatenation of every rank's `t` (equal sizes), on the current stream."""
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError("DirectComm.all_gather: contiguous device tensors only")
+        out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+        st = torch.cuda.current_stream(t.device).cuda_stream
+        _check(_load().ncclAllGather(t.data_ptr(), out.data_ptr(), t.numel(), _DT[t.dtype], self.comm, C.c_void_p(st)),
+               "ncclAllGather")
+        self.calls += 1
+        return out
 
     def close(self):
         if self.comm:

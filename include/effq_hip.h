@@ -187,6 +187,29 @@ int effq_fp_bracket_stats(const float* x, size_t n, int levels, double lo, doubl
                           void* stream);
 int effq_fp_bracket_update(size_t n, int levels, double lo, double hi, double tol, int max_iter,
                            effq_fp_state* state_dev, void* ws, void* stream);
+/* Data-parallel ranks, "gather once": after a few all-reduced iterations (stats / update above) a rank's shard is, under
+ * the current bracket, four integer tallies of the decided values + the list of the undecided ones.
+ *   export: out (effq_fp_bracket_export_words() int64): [0..3] = the tallies, [4] = the list's length (-1: no list yet, -2:
+ *           the current bracket is a horizon the iterates are meant to leave - many levels - so not worth exchanging),
+ *           [5], [6] = the bit patterns of the bracket [blo, bhi] the tallies and the list are valid under (ranks plan on
+ *           their own shard: brackets may differ), the rest scratch; list_out[0 .. list_cap) = the list, zero-filled behind
+ *           it (all zeros if there is none or it does not fit).  The caller all-reduces a pack {tallies[4], then per rank
+ *           (length, blo bits, bhi bits)} and all-gathers the list_cap floats of every rank (zero padding is harmless for
+ *           the unsigned quantiser lo = 0: an exact zero has level 0 at every scale);
+ *   import: sets up ws_dst (effq_fp_bracket_ws_bytes(world * list_cap)) as a fit over the gathered lists with the summed
+ *           tallies as its constant part and the iterates / unit of ws_src, valid under the INTERSECTION of the ranks'
+ *           brackets; effq_fp_bracket_run(gathered, world * list_cap, ..., ws_dst) then finishes WITHOUT collectives,
+ *           bit-identically on every rank.  Whether the exchange is usable (every list fitted, the iterate lies in the
+ *           intersection) is decided on the device - the host never needs the lengths: if not, or once an iterate leaves
+ *           that bracket, state.done = 4 (the launches that follow are no-ops) and the caller goes on with stats / update
+ *           on the rank's own workspace after effq_fp_bracket_rebase. */
+size_t effq_fp_bracket_export_words(void);
+int effq_fp_bracket_export(const void* ws, size_t n, long long* out, float* list_out, size_t list_cap, void* stream);
+int effq_fp_bracket_import(const void* ws_src, size_t n_src, const long long* pack_dev, int world, size_t list_cap,
+                           effq_fp_state* state_dev, void* ws_dst, size_t ws_dst_bytes, void* stream);
+/* after state.done = 4: clears it and makes the rank's OWN workspace start its next pass from the base (its list and
+ * tallies belong to a bracket the iterates have moved on from while the imported fit ran) */
+int effq_fp_bracket_rebase(effq_fp_state* state_dev, void* ws, size_t n, void* stream);
 /* Sticky device-side check used by stream-resident loops: *err_flag_dev = 2 (cap hit; the reference
  * raises, layer_helper.py:62-64) or 3 (not finished) unless state.done == 1. */
 int effq_fp_check(const effq_fp_state* state_dev, int32_t* err_flag_dev, void* stream);

@@ -9,6 +9,14 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = "cuda:0"
+if os.environ.get("EFFQ_DP_FORCE", "0") == "1" or os.environ.get("EFFQ_INIT_PG"):        # every data-parallel collective on a 1-rank RCCL group
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29677")
+    torch.cuda.set_device(0)
+    if os.environ.get("EFFQ_INIT_PG", "nccl") == "gloo":
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    else:
+        dist.init_process_group("nccl", rank=0, world_size=1)
 args = Cf.make_args(Cf.BRATS_NET, L, L)
 QConv, _, kwQ = Cf.get_conv_class(args)
 model = Cf.get_model_cube(args, QConv, kwQ)[0]["model"]

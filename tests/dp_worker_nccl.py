@@ -33,7 +33,7 @@ def main():
     out = sys.argv[1]
     vols = torch.randn(2, 1, 16, 16, 16, generator=torch.Generator().manual_seed(5))
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    dist.init_process_group("nccl", rank=0, world_size=1)
     assert dist.get_backend() == "nccl"
     from efficientq_amd.qconv import SumReducer
     from efficientq_amd import rccl
