@@ -31,6 +31,10 @@ OVERLAP_LOSS_DEFAULT = _os.environ.get("EFFQ_OVERLAP_LOSS", "1") != "0"
 GRAM_LOSS_DEFAULT = _os.environ.get("EFFQ_GRAM_LOSS", "1") != "0"
 GRAM_LOSS_MAX_N = int(_os.environ.get("EFFQ_GRAM_LOSS_MAX_N", "1729"))
 GRAM_LOSS_I8 = _os.environ.get("EFFQ_GRAM_LOSS_I8", "1") != "0"     # wide layers: the quadratic form on the i8 matrix cores
+# ... up to this system size: measured per calibration, BraTS (n = 3457, 6913) 674 -> 657 ms with it; LiTS with its
+# 512-channel layers (n = 13825) included 2110 -> 2169 ms (5.4 ms per group of 8 iterates beside a chain that is itself
+# slowed by three concurrent 57 ms inverses), so those keep the integer conv pass
+GRAM_LOSS_I8_MAX_N = int(_os.environ.get("EFFQ_GRAM_LOSS_I8_MAX_N", "8000"))
 
 
 def get_ops(device):
@@ -402,7 +406,8 @@ class EfficientQConvHIP(PTQConv):
                       yn.numel() // c2 >= 8 * n_sys)
         # ... and on the wide layers (n above GRAM_LOSS_MAX_N: the fp64 evaluation would cost more than the conv pass) with
         # the quadratic form on the i8 matrix cores: both of its factors are small integers there (effq_gram_loss_i8)
-        use_gl8 = bool(use_gi8 and GRAM_LOSS_DEFAULT and GRAM_LOSS_I8 and not use_gl and n_sys > GRAM_LOSS_MAX_N and
+        use_gl8 = bool(use_gi8 and GRAM_LOSS_DEFAULT and GRAM_LOSS_I8 and not use_gl and
+                       GRAM_LOSS_MAX_N < n_sys <= GRAM_LOSS_I8_MAX_N and
                        getattr(ops, "gram_loss_i8_supported", lambda *a: False)(c2, n_sys, has_b, self.qlvl_w))
         if use_gi8 and (use_gl or use_gl8):
             A0, B0, Au, Bu = ops.gram_i8(xidx, att_cls, yn, geom, has_b, self.alpha_act.data, self.qlvl_act,
