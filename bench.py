@@ -546,7 +546,7 @@ def main():
         if world > 1 and comm is not None:
             comm.barrier(device)
         elif world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize(device)
 
     for i in range(a.warmup):

@@ -28,6 +28,7 @@ DP_GATHER_MAX_BYTES = int(_os.environ.get("EFFQ_DP_GATHER_MAX_BYTES", str(128 <<
 BUCKET_FIXED_POINT = _os.environ.get("EFFQ_BUCKET_FP", "1") != "0"
 TRAJ_FIXED_POINT = _os.environ.get("EFFQ_FP_TRAJ", "1") != "0"
 SIDE2_STREAM = _os.environ.get("EFFQ_SIDE2", "1") != "0"
+SIDE_STREAM = _os.environ.get("EFFQ_SIDE", "1") != "0"      # 0: every inverse on the main stream, ahead of the loop (diagnostic)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -692,9 +693,10 @@ class HipOps:
         # streams by
         prox = self._workspace("prox", self.lib.effq_prox_ws_bytes(c2, n))
         inv = self._workspace("inv", self.lib.effq_spd_inverse_ws_bytes(n))
-        inv_side = self._workspace("inv_side", self.lib.effq_spd_inverse_ws_bytes(n)) if n_inv > 1 else None
+        inv_side = (self._workspace("inv_side", self.lib.effq_spd_inverse_ws_bytes(n))
+                    if n_inv > 1 and SIDE_STREAM else None)
         inv_side2 = (self._workspace("inv_side2", self.lib.effq_spd_inverse_ws_bytes(n))
-                     if n_inv > 2 and SIDE2_STREAM else None)
+                     if n_inv > 2 and SIDE2_STREAM and SIDE_STREAM else None)
         fpw = (self._workspace("fp_bucket", self.lib.effq_fp_bucket_ws_bytes(nw))
                if nw <= self.lib.effq_fp_bucket_max() and BUCKET_FIXED_POINT else None)
         # weight projection from the previous iteration's iterates (effq_fixed_point_traj)

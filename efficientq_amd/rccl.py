@@ -71,6 +71,32 @@ def _check(rc: int, what: str):
         raise RuntimeError(f"{what} failed: {_load().ncclGetErrorString(rc).decode(errors='replace')}")
 
 
+def exchange_unique_id(raw, rank: int, world: int, group=None) -> bytes:
+    """Rank 0's 128 bytes on every rank of `group` (no device work: runs on any backend; covered on gloo by
+    tests/dp_worker.py)."""
+    import torch.distributed as dist
+    if world > 1:
+        if group is None:
+            # through the rendezvous store (plain TCP): the framework's own NCCL communicator - and the extra HIP
+            # streams it brings, which alias the calibration's streams onto shared hardware queues (measured: +20 % per
+            # calibration with an eagerly initialised "nccl" group that is never used) - is never created
+            global _uid_seq
+            store = dist.distributed_c10d._get_default_store()
+            key = f"effq_rccl_uid_{_uid_seq}"
+            _uid_seq += 1
+            if rank == 0:
+                store.set(key, raw)
+            raw = store.get(key)
+        else:
+            box = [raw]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group)
+            raw = box[0]
+    raw = bytes(raw)
+    if len(raw) != NCCL_UNIQUE_ID_BYTES:
+        raise RuntimeError(f"exchange_unique_id: {len(raw)} bytes arrived, expected {NCCL_UNIQUE_ID_BYTES}")
+    return raw
+
+
 class DirectComm:
     """One RCCL communicator over the ranks of a torch.distributed group, used for in-stream SUM all-reduces."""
 
@@ -82,22 +108,7 @@ class DirectComm:
         if self.rank == 0:
             _check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
         raw = C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else None
-        if self.world > 1:
-            if group is None:
-                # through the rendezvous store (plain TCP): the framework's own NCCL communicator - and the extra HIP
-                # streams it brings, which alias the calibration's streams onto shared hardware queues (measured: +20 % per
-                # calibration with an eagerly initialised "nccl" group that is never used) - is never created
-                global _uid_seq
-                store = dist.distributed_c10d._get_default_store()
-                key = f"effq_rccl_uid_{_uid_seq}"
-                _uid_seq += 1
-                if self.rank == 0:
-                    store.set(key, raw)
-                raw = store.get(key)
-            else:
-                box = [raw]
-                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group)
-                raw = box[0]
+        raw = exchange_unique_id(raw, self.rank, self.world, group)
         C.memmove(C.byref(uid), bytes(raw), NCCL_UNIQUE_ID_BYTES)
         self.comm = C.c_void_p()
         _check(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
@@ -142,17 +153,49 @@ class DirectComm:
 _comms = {}
 
 
+_agree_seq = 0
+
+
+def _all_ranks_ok(ok: bool, group) -> bool:
+    """True when EVERY rank of the default group reports `ok` (through the rendezvous store: no device work)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1 or group is not None:
+        return ok
+    global _agree_seq
+    store = dist.distributed_c10d._get_default_store()
+    key = f"effq_rccl_ok_{_agree_seq}"
+    _agree_seq += 1
+    store.set(f"{key}_{dist.get_rank()}", b"1" if ok else b"0")
+    return all(bytes(store.get(f"{key}_{r}")) == b"1" for r in range(world))
+
+
 def get_comm(group=None) -> Optional[DirectComm]:
-    """The communicator of `group` (created collectively on first use), or None when EFFQ_RCCL_DIRECT=0."""
+    """The communicator of `group` (created collectively on first use), or None when EFFQ_RCCL_DIRECT=0 - or when any rank
+    failed to create it: then EVERY rank gets None and the collectives go through torch.distributed's own RCCL
+    communicator (same library, two stream hops per call), with a warning on stderr."""
     if os.environ.get("EFFQ_RCCL_DIRECT", "1") == "0":
         return None
     key = id(group) if group is not None else 0
     if key not in _comms:
-        _comms[key] = DirectComm(group)
+        comm, err = None, None
+        try:
+            comm = DirectComm(group)
+        except Exception as e:           # noqa: BLE001 - whatever went wrong, the ranks must agree on the path they take
+            err = e
+        if not _all_ranks_ok(comm is not None, group):
+            import sys
+            print(f"[efficientq_amd.rccl] direct RCCL communicator unavailable ({err if err else 'another rank failed'}): "
+                  "falling back to torch.distributed collectives", file=sys.stderr, flush=True)
+            if comm is not None:
+                comm.close()
+            comm = None
+        _comms[key] = comm
     return _comms[key]
 
 
 def close_all():
     for c in _comms.values():
-        c.close()
+        if c is not None:
+            c.close()
     _comms.clear()

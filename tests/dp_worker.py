@@ -43,6 +43,17 @@ def main():
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     assert dist.get_world_size() == 2
+    # the RCCL unique id travels through the rendezvous store (efficientq_amd/rccl.py): 128 bytes with NULs inside, twice
+    from efficientq_amd import rccl
+    for rep in range(2):
+        want = bytes((7 * i + rep) % 256 if i % 5 else 0 for i in range(rccl.NCCL_UNIQUE_ID_BYTES))
+        got = rccl.exchange_unique_id(want if rank == 0 else None, rank, 2, None)
+        assert got == want, (rank, rep)
+    sub = dist.new_group([0, 1])
+    got = rccl.exchange_unique_id(want if rank == 0 else None, rank, 2, sub)
+    assert got == want
+    assert rccl._all_ranks_ok(True, None) is True
+    assert rccl._all_ranks_ok(rank == 0, None) is False           # one rank failed: every rank learns it
     r = run(vols[rank:rank + 1])          # shard: one volume per rank
     torch.save(r, f"{out}_rank{rank}.pt")
     dist.barrier()
