@@ -6,7 +6,8 @@ from efficientq_amd.hip_ops import get_ops
 
 ops = get_ops("cuda:0")
 gen = torch.Generator().manual_seed(0)
-for n, L in [(96, 256), (3456, 256), (2048, 4), (8192, 4), (16384, 4), (27648, 4), (32768, 4), (27648, 16), (110592, 4), (442368, 4), (1769472, 4), (7077888, 4)]:
+CASES = [tuple(int(x) for x in c.split(':')) for c in sys.argv[1:]]
+for n, L in CASES or [(96, 256), (3456, 256), (2048, 4), (8192, 4), (16384, 4), (27648, 4), (32768, 4), (27648, 16), (110592, 4), (442368, 4), (1769472, 4), (7077888, 4)]:
     w = (torch.randn(n, generator=gen) * 0.05).cuda()
     du = (torch.randn(n, generator=gen) * 0.005).cuda()
     v = torch.empty(n, device="cuda:0")
