@@ -188,9 +188,17 @@ __device__ __forceinline__ void fpt_phase1(FptSmem& sm, const float (&vv)[EPT], 
     __syncthreads();
   }
   // (b) the worklist, one value per lane and round: per slot, the two ends of the wide bracket, then of the narrow one.
-  // The contributions of a round are summed over the wave at once and LANE j keeps the totals of slot j (32 running sums
-  // per thread made this kernel's register file: 64 VGPRs)
-  unsigned long long aw_ru = 0, aw_ct = 0, ar_ru = 0, ar_ct = 0;
+  // (Running sums per thread and slot, reduced once at the end: summing each round over the wave at once and keeping the
+  // totals of slot j in lane j saves 66 VGPRs - 232 -> 166, still one workgroup per CU - and measured 4 us SLOWER per call
+  // inside the calibration: the DPP chains then sit between the classifications of consecutive slots.)
+  long long tw_ru[FPT_SLOTS], tw_ct[FPT_SLOTS], tr_ru[FPT_SLOTS], tr_ct[FPT_SLOTS];
+#pragma unroll
+  for (int j = 0; j < FPT_SLOTS; ++j) {
+    tw_ru[j] = 0;
+    tw_ct[j] = 0;
+    tr_ru[j] = 0;
+    tr_ct[j] = 0;
+  }
   const unsigned n_work = warm ? sm.nw : 0u;
   const bool wave_works = (unsigned)(wid * 64) < n_work;          // (wave-uniform)
   if (wave_works) {
@@ -198,40 +206,26 @@ __device__ __forceinline__ void fpt_phase1(FptSmem& sm, const float (&vv)[EPT], 
       const unsigned idx = i0 + (unsigned)lane;
       const bool have = idx < n_work;
       const float v = have ? sm.work[idx] : 0.0f;
-      const unsigned long long u = have ? (unsigned long long)__double2ll_rn((double)v * inv_q) : 0ull;
       unsigned nmask = 0u, rmask = 0u;
+      if (have) {
+        const long long u = __double2ll_rn((double)v * inv_q);
 #pragma unroll
-      for (int j = 0; j < FPT_SLOTS; ++j) {
-        if (j < K) {                             // (uniform)
-          long long x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-          if (have) {
+        for (int j = 0; j < FPT_SLOTS; ++j) {
+          if (j < K) {
             const int ra = level_end(v, 4 * j), rb = level_end(v, 4 * j + 3);
             if (ra == rb) {
-              x0 = (long long)((unsigned long long)(long long)ra * u);       // mod 2^64 (fpt_add_wrap)
-              x1 = fpt_pack(ra);
+              tw_ru[j] = fpt_add_wrap(tw_ru[j], ra, u);
+              tw_ct[j] += fpt_pack(ra);
             } else {
               const int na = level_end(v, 4 * j + 1), nb = level_end(v, 4 * j + 2);
               if (na == nb) {
-                x2 = (long long)((unsigned long long)(long long)na * u);
-                x3 = fpt_pack(na);
+                tr_ru[j] = fpt_add_wrap(tr_ru[j], na, u);
+                tr_ct[j] += fpt_pack(na);
                 rmask |= 1u << j;
               } else {
                 nmask |= 1u << j;
               }
             }
-          }
-          const long long q0 = fpt_wave_sum(x0), q1 = fpt_wave_sum(x1);
-          long long q2 = 0, q3 = 0;
-          // ring contributions are rare: skip their sums when the wave has none (level 0 packs to 0 and adds 0)
-          if (__builtin_amdgcn_ballot_w64(x3 != 0) != 0ull) {
-            q2 = fpt_wave_sum(x2);
-            q3 = fpt_wave_sum(x3);
-          }
-          if (lane == j) {
-            aw_ru += (unsigned long long)q0;
-            aw_ct += (unsigned long long)q1;
-            ar_ru += (unsigned long long)q2;
-            ar_ct += (unsigned long long)q3;
           }
         }
       }
@@ -267,11 +261,26 @@ __device__ __forceinline__ void fpt_phase1(FptSmem& sm, const float (&vv)[EPT], 
       sm.red[0][wid] = c0s;
       sm.red[1][wid] = c1s;
     }
-    if (lane < K) {
-      sm.red[2 + 4 * lane + 0][wid] = (long long)aw_ru;
-      sm.red[2 + 4 * lane + 1][wid] = (long long)aw_ct;
-      sm.red[2 + 4 * lane + 2][wid] = (long long)ar_ru;
-      sm.red[2 + 4 * lane + 3][wid] = (long long)ar_ct;
+#pragma unroll
+    for (int j = 0; j < FPT_SLOTS; ++j) {
+      if (j < K) {                               // (uniform)
+        long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        if (wave_works) {
+          q0 = fpt_wave_sum(tw_ru[j]);
+          q1 = fpt_wave_sum(tw_ct[j]);
+          // ring tallies are empty for most waves: skip their sums then (wave-uniform)
+          if (__builtin_amdgcn_ballot_w64(tr_ct[j] != 0) != 0ull) {
+            q2 = fpt_wave_sum(tr_ru[j]);
+            q3 = fpt_wave_sum(tr_ct[j]);
+          }
+        }
+        if (lane == 0) {
+          sm.red[2 + 4 * j + 0][wid] = q0;
+          sm.red[2 + 4 * j + 1][wid] = q1;
+          sm.red[2 + 4 * j + 2][wid] = q2;
+          sm.red[2 + 4 * j + 3][wid] = q3;
+        }
+      }
     }
   }
   __syncthreads();
