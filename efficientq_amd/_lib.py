@@ -70,7 +70,7 @@ class AdmmRunArgs(C.Structure):
                 ("stream_main", C.c_void_p), ("stream_loss", C.c_void_p), ("stream_side", C.c_void_p),
                 ("stream_side2", C.c_void_p), ("inv_ws_side2", C.c_void_p), ("inv_ws_side2_bytes", C.c_size_t),
                 ("loss_Au", C.c_void_p), ("loss_Bu", C.c_void_p), ("loss_syy", C.c_void_p),
-                ("loss_planes", C.c_void_p), ("loss_nplanes", C.c_int32)]
+                ("loss_planes", C.c_void_p), ("loss_nplanes", C.c_int32), ("res_ring", C.c_void_p)]
 
 
 class ProfRecord(C.Structure):

@@ -175,6 +175,28 @@ __global__ __launch_bounds__(256) void k_select_best(const double* __restrict__ 
   }
 }
 
+// lwq_verbose (EfficientQConv.py:114-116): sum (w* - G)^2 and sum (G - G0)^2 of an iteration -> res[0], res[1] (the host
+// takes the roots and multiplies the second by rho).  A diagnostic: fp64 atomics, printed to four decimals.
+__global__ __launch_bounds__(256) void k_admm_residuals(const float* __restrict__ wstar, const float* __restrict__ G,
+                                                        const float* __restrict__ G0, size_t n, double* __restrict__ res) {
+  __shared__ double sh[2][4];
+  double a = 0.0, b = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double p = (double)wstar[i] - (double)G[i], q = (double)G[i] - (double)G0[i];
+    a += p * p;
+    b += q * q;
+  }
+  a = wave_sum_f64_dpp(a);
+  b = wave_sum_f64_dpp(b);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[0][wid] = a;
+    sh[1][wid] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) atomicAdd(res + threadIdx.x, (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]));
+}
+
 }  // namespace effq
 using namespace effq;
 
@@ -309,6 +331,7 @@ int effq_admm_run(const effq_admm_run_args* a) {
   hipEvent_t ev_fork = nullptr, ev_join_loss = nullptr, ev_join_side = nullptr;
 
   ADMM_HIP(hipMemsetAsync(a->dual, 0, nw * sizeof(float), s_main));                 // dual <- 0 (EfficientQConv.py:40)
+  if (a->res_ring != nullptr) ADMM_HIP(hipMemsetAsync(a->res_ring, 0, 2 * (size_t)a->iters * sizeof(double), s_main));
   if (traj) ADMM_HIP(hipMemsetAsync(a->fp_pred, 0, effq_fp_traj_pred_bytes(), s_main));   // nothing known about this layer
   // the inverse the first iterations need, on the main stream; the later ones on the side stream, which starts at once,
   // beside the first inverse (all of them only read A0): with n = 13825 an inverse takes longer than the 50 iterations it has
@@ -509,6 +532,12 @@ int effq_admm_run(const effq_admm_run_args* a) {
         bm_ready = false;
       }
       p_pr.close();
+    }
+    if (a->res_ring != nullptr) {                 // lwq_verbose: residuals of this iteration (w* is overwritten by the next)
+      size_t nb = (nw + 1023) / 1024;
+      if (nb > 256) nb = 256;
+      hipLaunchKernelGGL(k_admm_residuals, dim3((unsigned)nb), dim3(256), 0, s_main, a->wstar, G, G_prev, nw,
+                         a->res_ring + 2 * (size_t)i);
     }
     // ---- the losses (loss stream), in groups of LOSS_GROUP iterates ----
     // An event record is a barrier packet in the main queue: the next chain kernel starts ~7 us later than it would

@@ -642,7 +642,7 @@ class HipOps:
     # -- the whole ADMM loop of a layer in one binding call ---------------------------------------------
     def admm_run(self, A0, B0, W0, b0, geom: Geom, y_ndhwc, *, xq=None, xidx=None, act_alpha=None, act_levels: int = 0,
                  loss_kind: int = 0, rho: float, rho_max: float, eta: float, iters: int, period: int, levels: int,
-                 overlap: bool = True, loss_gram=None):
+                 overlap: bool = True, loss_gram=None, residuals: bool = False):
         """effq_admm_run: enqueue `iters` ADMM iterations (chain on the current stream, per-iteration loss on the
         loss stream, later inverses on the side stream).  Returns a handle with the rings and `hist` (iters x 2
         device doubles, sums of squared errors); no host synchronisation.
@@ -686,6 +686,7 @@ class HipOps:
         r.state_ring = torch.zeros(iters, 5, dtype=torch.float64, device=dev)
         r.hist = torch.zeros(iters, 2, dtype=torch.float64, device=dev)
         r.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        r.res = torch.zeros(iters, 2, dtype=torch.float64, device=dev) if residuals else None     # lwq_verbose
         main = torch.cuda.current_stream(dev)
         loss_s = self.loss_stream() if overlap else None
         side_s = self.side_stream()
@@ -738,6 +739,7 @@ class HipOps:
         a.dual, a.wstar, a.v = p(r.dual), p(r.wstar), p(r.v)
         a.G_ring, a.Gq_ring, a.b_ring = p(r.G_ring), p(r.Gq_ring), p(r.b_ring)
         a.state_ring, a.hist, a.err_flag = p(r.state_ring), p(r.hist), p(r.err)
+        a.res_ring = p(r.res)
         a.ainv_pool, a.n_ainv = p(r.ainv), n_inv
         a.prox_ws, a.prox_ws_bytes = p(prox), prox.numel()
         a.red_ws = p(self._red_ws)

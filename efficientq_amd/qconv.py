@@ -443,6 +443,8 @@ class EfficientQConvHIP(PTQConv):
         t_loop0 = _time.perf_counter()
         loss_kind = 1 if use_i8 else (2 if use_i8s else 0)
         kw = dict(loss_gram=loss_gram) if loss_gram is not None else {}
+        if self.lwq_verbose:
+            kw['residuals'] = True        # the per-iteration residual norms of the reference's progress line (:114-127)
         run = ops.admm_run(A0, B0, W0, b0, geom, yn, xq=xq, xidx=xidx, act_alpha=self.alpha_act.data,
                            act_levels=self.qlvl_act, loss_kind=loss_kind, rho=rho, rho_max=rho_m, eta=eta,
                            iters=self.lwq_iter, period=RHO_PERIOD, levels=self.qlvl_w,
@@ -465,6 +467,16 @@ class EfficientQConvHIP(PTQConv):
         if _os.environ.get("EFFQ_FP_TRAJ_STATS") and getattr(run, "fp_pred", None) is not None:     # diagnostic
             print(f"[fp_traj] {getattr(self, 'name', '?')}: {ops.read_fp_pred(run.fp_pred)}", flush=True)
         a_w, w_iters, hist, best_h = info["alpha_w"], info["w_iters"], info["hist"], info["best"]
+        if self.lwq_verbose and getattr(run, "res", None) is not None:
+            # "print every 10 admm iters" (EfficientQConv.py:124-127), after the loop: the iterations are enqueued as a whole
+            res, r_i = run.res.cpu(), rho
+            for i in range(self.lwq_iter):
+                if i % 10 == 0:
+                    print(f'ADMM iter {i + 1}: primal residual = {float(res[i, 0]) ** 0.5:.4f}, '
+                          f'dual residual = {r_i * float(res[i, 1]) ** 0.5:.4f}, rho = {r_i:.4f}, eta = {eta:.4f}, '
+                          f'loss = {hist[i] / (y_dim * 1.0):.7f}.')
+                if i % RHO_PERIOD == 0:
+                    r_i = r_i * 2 if r_i * 2 <= rho_m else rho_m
         if info["err"] >= 1000:
             raise RuntimeError(f'{self.name}: the unweighted Gram system is not the integer system effq_gram_loss_i8 '
                                f'expects (flag {info["err"] // 1000})')

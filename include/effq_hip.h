@@ -441,6 +441,10 @@ typedef struct effq_admm_run_args {
    * as above, loss_planes / loss_nplanes from effq_gram_loss_i8_prepare, Gq_ring and act_alpha_dev as for loss_kind 1;
    * conv_ws = effq_gram_loss_i8_ws_bytes() zero-filled once. */
   const int8_t* loss_planes; int32_t loss_nplanes;
+  /* lwq_verbose (EfficientQConv.py:114-127): iters x 2 device doubles, sum (w* - G)^2 and sum (G - G_prev)^2 of every
+   * iteration (the primal residual is the root of the first, the dual residual rho times the root of the second); NULL: not
+   * computed (one small launch per iteration) */
+  double* res_ring;
 } effq_admm_run_args;
 /* 1 if effq_admm_run takes the trajectory weight projection (effq_fixed_point_traj) for a layer of nw weights at
  * w_levels levels - the caller then passes fp_pred (effq_fp_traj_pred_bytes(), zero-filled) and fp_traj_ws

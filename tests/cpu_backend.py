@@ -134,7 +134,7 @@ class OracleOps:
 
     # the whole loop (the product issues it through effq_admm_run; same order of operations, EfficientQConv.py:99-144)
     def admm_run(self, A0, B0, W0, b0, geom, y_ndhwc, *, xq=None, xidx=None, act_alpha=None, act_levels=0,
-                 loss_kind=0, rho, rho_max, eta, iters, period, levels, overlap=True):
+                 loss_kind=0, rho, rho_max, eta, iters, period, levels, overlap=True, residuals=False):
         from types import SimpleNamespace
         has_b = b0 is not None
         c2 = B0.shape[0]
@@ -144,6 +144,7 @@ class OracleOps:
         r = SimpleNamespace(iters=iters, nw=W0.numel(), c2=c2, has_b=has_b, G_ring=[], b_ring=[] if has_b else None,
                             hist=torch.zeros(iters, 2, dtype=torch.float64), w_iters=[], alpha_w=None)
         st = self.new_fp_state()
+        r.res = torch.zeros(iters, 2, dtype=torch.float64) if residuals else None
         for i in range(iters):
             A = self.spd_inverse(A0, has_b, rho, eta)
             bstar = torch.empty(c2) if has_b else None
@@ -154,6 +155,9 @@ class OracleOps:
                 dual_div = 2.0 if rho * 2 <= rho_max else rho_max / rho
             Gn = torch.empty_like(W0)
             self.admm_project_dual(v, wstar, st, levels, Gn, dual, dual_div)
+            if residuals:
+                r.res[i, 0] = ((wstar.double() - Gn.double()) ** 2).sum()
+                r.res[i, 1] = ((Gn.double() - G.double()) ** 2).sum()
             _, sq = self.conv_step(xq, Gn, bstar, geom, y_ndhwc)
             r.hist[i] = sq
             r.G_ring.append(Gn)

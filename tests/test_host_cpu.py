@@ -163,6 +163,37 @@ def _layer_from_gold(g, tag):
     return conv, T(g[f"{tag}_x"]), (L_w, L_a, bool(q_act))
 
 
+def _progress_lines(text):
+    import re
+    pat = re.compile(r"ADMM iter (\d+): primal residual = ([0-9.]+), dual residual = ([0-9.]+), rho = ([0-9.]+), "
+                     r"eta = ([0-9.]+), loss = ([0-9.]+)\.")
+    return [(int(m[1]), float(m[2]), float(m[3]), float(m[4]), float(m[5]), float(m[6])) for m in pat.finditer(text)]
+
+
+def test_lwq_verbose_prints_the_reference_progress_line(gold, monkeypatch, capsys):
+    """EfficientQConv.py:114-127: 'ADMM iter i+1: primal residual = ..., dual residual = ..., rho = ..., eta = ..., loss = ...'
+    every 10 iterations, with ||w* - G||, rho ||G - G0|| and the iteration's MSE - against the oracle's histories."""
+    import oracle.effq_oracle as O
+    cpu_backend.install(monkeypatch)
+    g = gold("g5_layer_ptq.npz")
+    conv, x, (L_w, L_a, q_act) = _layer_from_gold(g, "L4")
+    conv.lwq_verbose = True
+    conv.set_quantizing()
+    with torch.no_grad():
+        conv(x)
+    lines = _progress_lines(capsys.readouterr().out)
+    assert [l[0] for l in lines] == list(range(1, 200, 10))
+    c1, c2, k, pad, N, S, _, _, _, with_mask = [int(v) for v in g["L4_meta"]]
+    ref = O.calibrate_layer(x, T(g["L4_y"]), T(g["L4_w_in"]), T(g["L4_b_in"]), tuple(int(v) for v in g["L4_stride"]), pad,
+                            qlvl_w=L_w, qlvl_act=L_a, q_act=q_act, mask_pyramid=conv.mask_pyramid if with_mask else None)
+    for it, pres, dres, rho, eta, loss in lines:
+        i = it - 1
+        assert abs(rho - ref.rho_history[i]) <= 1e-4 * ref.rho_history[i] + 1e-4
+        assert abs(pres - ref.primal_res[i]) <= 2e-3 * ref.primal_res[i] + 5e-3, (i, pres, ref.primal_res[i])
+        assert abs(dres - ref.dual_res[i]) <= 2e-3 * ref.dual_res[i] + 5e-3, (i, dres, ref.dual_res[i])   # (late: a flip or none)
+        assert abs(loss - ref.loss_history[i]) <= 1e-3 * ref.loss_history[i] + 1e-7
+
+
 @pytest.mark.parametrize("tag", ["L4", "L16", "first", "k1"])
 def test_product_ptq_on_oracle_backend_matches_reference(gold, monkeypatch, tag):
     cpu_backend.install(monkeypatch)

@@ -51,6 +51,32 @@ def test_layer_calibration_matches_reference(gold, tag):
     assert abs(tr["best_mse"] - float(g[f"{tag}_loss_hist"].min())) <= 1e-3 * float(g[f"{tag}_loss_hist"].min())
 
 
+def test_lwq_verbose_progress_line_on_the_device(gold, capsys):
+    """The reference's progress line (EfficientQConv.py:114-127) from the HIP path: residual norms of every iteration from
+    one small launch per iteration (effq_admm_run_args.res_ring), printed after the loop; against the oracle."""
+    import oracle.effq_oracle as O
+    from tests.test_host_cpu import _progress_lines
+    g = gold("g5_layer_ptq.npz")
+    conv, x, (L_w, L_a, q_act) = _layer_from_gold(g, "L4")
+    conv.lwq_verbose = True
+    _to_dev(conv)
+    conv.set_quantizing()
+    with torch.no_grad():
+        conv(x.to(DEV))
+    lines = _progress_lines(capsys.readouterr().out)
+    assert [l[0] for l in lines] == list(range(1, 200, 10))
+    c1, c2, k, pad, N, S, _, _, _, with_mask = [int(v) for v in g["L4_meta"]]
+    mp = [m.cpu() for m in conv.mask_pyramid] if with_mask else None
+    ref = O.calibrate_layer(x, T(g["L4_y"]), T(g["L4_w_in"]), T(g["L4_b_in"]), tuple(int(v) for v in g["L4_stride"]), pad,
+                            qlvl_w=L_w, qlvl_act=L_a, q_act=q_act, mask_pyramid=mp)
+    for it, pres, dres, rho, eta, loss in lines:
+        i = it - 1
+        assert abs(rho - ref.rho_history[i]) <= 1e-4 * ref.rho_history[i] + 1e-4
+        assert abs(pres - ref.primal_res[i]) <= 5e-3 * ref.primal_res[i] + 5e-3, (i, pres, ref.primal_res[i])
+        assert abs(dres - ref.dual_res[i]) <= 5e-3 * ref.dual_res[i] + 5e-3, (i, dres, ref.dual_res[i])   # (late: a flip or none)
+        assert abs(loss - ref.loss_history[i]) <= 1e-3 * ref.loss_history[i] + 1e-7
+
+
 def _rel_mse(a, b):
     return (((a - b) ** 2).mean() / (b ** 2).mean()).item()
 
