@@ -108,6 +108,7 @@ SIGNATURES = {
     "effq_fp_bracket_update": (_I, [_SZ, _I, _D, _D, _D, _I, _P, _P, _P]),
     "effq_fp_traj_max": (_SZ, []),
     "effq_fp_traj_ws_bytes": (_SZ, [_SZ]),
+    "effq_spd_inverse_prepare": (_I, [_P]),
     "effq_fp_traj_pred_bytes": (_SZ, []),
     "effq_fixed_point_traj": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _P, _SZ, _P]),
     "effq_fixed_point_bucket_rec": (_I, [_P, _P, _P, _SZ, _I, _D, _D, _D, _I, _P, _P, _SZ, _P, _P]),

@@ -1317,6 +1317,14 @@ static int gj_wide_sweep(double* A64, int npad, double* aux, hipStream_t st) {
   return EFFQ_OK;
 }
 
+// The helper stream of the 256-row sweep for `stream`, created NOW instead of at the first large inverse: streams take their
+// hardware queue in the order they are created, and a communicator created in between (RCCL brings streams of its own)
+// moved the calibration's streams onto shared queues (hip_ops.HipOps.warm_streams)
+int effq_spd_inverse_prepare(void* stream) {
+  GjWideCtx* ctx = nullptr;
+  return gj_wide_ctx(as_stream(stream), &ctx);
+}
+
 int effq_spd_inverse(const float* A0, int n, int has_bias, double rho, double eta, float* Ainv, void* ws,
                      size_t ws_bytes, void* stream) {
   EFFQ_CHECK_ARG(A0 && Ainv && ws && n > 0);

@@ -125,6 +125,25 @@ class HipOps:
             self._side2 = torch.cuda.Stream(self.device)
         return self._side2
 
+    def warm_streams(self):
+        """Create every stream the calibration uses NOW, in a fixed order: HIP hands out hardware queues in creation order
+        (4 by default), and streams that share one run their kernels one after the other.  Created lazily - after a
+        communicator had brought its own streams - the two side streams of the inverses landed on one queue (the later
+        inverses of the 256-channel layers 44 / 63 ms instead of 28 / 32, +5 % per calibration with a 1-rank RCCL group);
+        rccl.DirectComm calls this before ncclCommInitRank."""
+        if getattr(self, "_warm", False):
+            return
+        main = torch.cuda.current_stream(self.device)
+        # which streams get their helper, in which order, is empirical (per calibration with a 1-rank RCCL group, one box: none
+        # 693 ms, main / loss / side / side2 675, main / side / side2 - the order of a run without a communicator - 691; plain
+        # run 657; GPU_MAX_HW_QUEUES = 6 / 8: 766 / 753).  EFFQ_WARM_ORDER = 0 / 1 / 2 selects them (tuning aid)
+        order = _os.environ.get("EFFQ_WARM_ORDER", "1")
+        loss, side, side2 = self.loss_stream(), self.side_stream(), self.side_stream2()
+        sts = () if order == "0" else (main, loss, side, side2) if order == "1" else (main, side, side2)
+        for st in sts:
+            check(self.lib.effq_spd_inverse_prepare(st.cuda_stream), "effq_spd_inverse_prepare")
+        self._warm = True
+
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
         """Library workspace `key`, zero-filled when (re)allocated.  The fill is issued on the stream the NEXT op
         launches on (the pinned stream when one is set): a fill on torch's current stream would race with kernels

@@ -103,6 +103,9 @@ class DirectComm:
     def __init__(self, group=None):
         import torch.distributed as dist
         lib = _load()
+        # the calibration's own streams first: a communicator brings streams too, and hardware queues go by creation order
+        from . import hip_ops
+        hip_ops.get_ops(torch.device("cuda", torch.cuda.current_device())).warm_streams()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         uid = _UniqueId()
         if self.rank == 0:

@@ -299,6 +299,10 @@ size_t effq_att_classes_ws_bytes(void);
 int effq_att_classes(const float* att, long long V, int32_t* vox_list, int32_t* chunk_cls, float* cls_w_dev,
                      int32_t* info_host_out, void* ws, void* stream);
 
+/* Creates the helper stream the 256-row sweep keeps per caller stream (otherwise created by the first large inverse): call it
+ * for every stream inverses will run on BEFORE anything else creates streams (a communicator, a framework pool), so that the
+ * calibration's streams keep hardware queues of their own. */
+int effq_spd_inverse_prepare(void* stream);
 /* ---- a7: getAB + solve (solver.py:316-345) --------------------------------------
  * Ainv = (A0 + rho*I' + eta*I)^-1 in fp64 (I' has 0 on the bias diagonal), stored fp32 as n rows of
  * effq_ainv_ld(n) floats (row padding is zero; exactly symmetric).

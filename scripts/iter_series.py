@@ -11,6 +11,11 @@ from efficientq_amd import _lib, calibrate as K, config as Cf, synth, hip_ops
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 EVERY = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = "cuda:0"
+if os.environ.get("EFFQ_DP_FORCE", "0") == "1":        # every data-parallel collective on a 1-rank RCCL group
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29678")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
 args = Cf.make_args(Cf.BRATS_NET, 4, 4)
 QConv, _, kwQ = Cf.get_conv_class(args)
 model = Cf.get_model_cube(args, QConv, kwQ)[0]["model"]
@@ -35,7 +40,7 @@ for i in range(lib.effq_prof_count()):
     _lib.check(lib.effq_prof_read(i, C.byref(r)), "effq_prof_read")
     key = (r.c2, r.n)
     if r.kind == 5 and r.iter == -1:                 # the first inverse of a layer opens it
-        cur = dict(key=key, rows={}, inv=[], wait=0.0)
+        cur = dict(key=key, rows={}, inv=[], wait=0.0, waits=[])
         layers.append(cur)
     if cur is None:
         continue
@@ -44,14 +49,17 @@ for i in range(lib.effq_prof_count()):
         cur["inv"].append(round(r.ms, 2))
     elif k == "wait":
         cur["wait"] += r.ms
+        cur["waits"].append((r.iter, round(r.ms, 3)))
     else:
         cur["rows"].setdefault(r.iter, {})[k] = r.ms
 lib.effq_prof_enable(0)
 for L in layers:
     c2, n = L["key"]
     if n < 3000:
+        if L["wait"] > 0.3:
+            print(f"layer c2={c2} n={n}: inverses {L['inv']} ms, waits {L['wait']:.2f} ms  at (iteration, ms): {L['waits']}")
         continue
-    print(f"layer c2={c2} n={n}: inverses {L['inv']} ms, waits {L['wait']:.2f} ms")
+    print(f"layer c2={c2} n={n}: inverses {L['inv']} ms, waits {L['wait']:.2f} ms  at (iteration, ms): {L['waits']}")
     for it in sorted(L["rows"]):
         row = L["rows"][it]
         print(f"   it {it:3d}  " + "  ".join(f"{k} {row[k] * 1e3:7.1f} us" for k in ("prox", "fp", "proj", "loss") if k in row))
