@@ -30,6 +30,14 @@ float* effq_prox_bm(void* ws, int c2, int n, int* ldb);
 int effq_prox_solve_prebuilt(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
                              const float* dual, int c2, int n, int has_bias, double rho, double eta, float* wstar,
                              float* bstar, void* ws, size_t ws_bytes, void* stream);
+int effq_prox_solve_prebuilt_parts(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
+                                   const float* dual, int c2, int n, int has_bias, double rho, double eta, float* wstar,
+                                   float* bstar, void* ws, size_t ws_bytes, void* stream, const float** part_out,
+                                   int* nsplit_out, int* ldp_out);                      // solve.hip
+int effq_fixed_point_traj_parts(const float* part, int nsplit, int ldp, int c2, int nwrow, int has_bias, const float* dual,
+                                float* wstar_out, float* bstar_out, float* v_out, int levels, double lo, double hi, double tol,
+                                int max_iter, effq_fp_state* state_dev, void* pred_dev, void* ws, size_t ws_bytes,
+                                void* stream);                                          // fixed_point_traj.hip
 int effq_project_dual_checked(const float* v, const float* wstar, const effq_fp_state* state_dev, int levels, float* G,
                               float* dual, float dual_div, int8_t* Gq_out, size_t n, int32_t* err_flag_dev,
                               void* stream);   // quant_reduce.hip (internal)
@@ -445,10 +453,23 @@ int effq_admm_run(const effq_admm_run_args* a) {
     int8_t* Gq = a->Gq_ring ? a->Gq_ring + (size_t)i * nw : nullptr;
     float* bstar = has_b ? a->b_ring + (size_t)i * c2 : nullptr;
     effq_fp_state* st = a->state_ring + i;
+    // (rho changes at the end of iterations 0, period, 2 period ...: the iteration after sees a rescaled dual)
+    const bool after_rho = i > 0 && (i - 1) % a->rho_period == 0 && rho_changed_last;
+    // (iterations since rho last changed: the drift from call to call - and with it the length of the lists the
+    // trajectory kernel's single last workgroup has to scan - is largest right after a change)
+    const int since_rho = i - rho_changed_at;
+    const bool use_traj = traj && i > 1 && !(traj_rho_old && after_rho) && since_rho >= traj_after;
+    // ... and then the trajectory kernel adds the K slices of the product up in its prologue: one launch less
+    static const bool fuse_reduce = !(getenv("EFFQ_FUSE_REDUCE") && atoi(getenv("EFFQ_FUSE_REDUCE")) == 0);   // A/B switch
+    const float* parts = nullptr;
+    int parts_n = 1, parts_ld = 0;
     // ---- the chain (main stream) ----
     const bool prof = g_prof_every > 0 && !use_shift && (i % g_prof_every) == g_prof_every / 2;
     ProfScope p_prox(prof, PROF_PROX, i, a, s_main);
-    if (use_shift)
+    if (!use_shift && bm_ready && use_traj && fuse_reduce && c2 <= 512)
+      ADMM_RC(effq_prox_solve_prebuilt_parts(a->B0, Ainv, a->W0, a->b0, G_prev, a->dual, c2, n, has_b, rho, a->eta, a->wstar,
+                                             bstar, a->prox_ws, a->prox_ws_bytes, s_main, &parts, &parts_n, &parts_ld));
+    else if (use_shift)
       ADMM_RC(effq_prox_solve_shifted(a->B0, a->ainv_pool, a->W0, a->b0, G_prev, a->dual, c2, n, has_b, rho, a->eta,
                                       plan.rho[1], shift_terms(rho, a->eta, plan.rho[1]), a->wstar, bstar, a->prox_ws,
                                       a->prox_ws_bytes, s_main));
@@ -493,13 +514,13 @@ int effq_admm_run(const effq_admm_run_args* a) {
         }
       }
     }
-    // (rho changes at the end of iterations 0, period, 2 period ...: the iteration after sees a rescaled dual)
-    const bool after_rho = i > 0 && (i - 1) % a->rho_period == 0 && rho_changed_last;
     void* rec = traj ? a->fp_pred : nullptr;
-    // (iterations since rho last changed: the drift from call to call - and with it the length of the lists the
-    // trajectory kernel's single last workgroup has to scan - is largest right after a change)
-    const int since_rho = i - rho_changed_at;
-    if (traj && i > 1 && !(traj_rho_old && after_rho) && since_rho >= traj_after) {
+    if (use_traj && parts != nullptr) {
+      fuse_proj = false;
+      ADMM_RC(effq_fixed_point_traj_parts(parts, parts_n, parts_ld, c2, n - has_b, has_b ? 1 : 0, a->dual, a->wstar, bstar,
+                                          a->v, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st, a->fp_pred,
+                                          a->fp_traj_ws, a->fp_traj_ws_bytes, s_main));
+    } else if (use_traj) {
       fuse_proj = false;
       ADMM_RC(effq_fixed_point_traj(a->wstar, a->dual, a->v, nw, a->w_levels, -1.0, 1.0, a->tol, 100 * a->w_levels, st,
                                     a->fp_pred, a->fp_traj_ws, a->fp_traj_ws_bytes, s_main));

@@ -27,10 +27,22 @@
 
 namespace effq {
 
+// the K slices of the prox product, not yet added up: w*[r][k] = sum_z part[z * slab + r * ldp + k] in slice order
+// (k_prox_reduce4's order: same bits); b*[r] = the column nwrow of row r.  The trajectory kernel adds them in its
+// prologue - one launch per ADMM iteration less, and w* is written once instead of written, read and written.
+struct FptParts {
+  const float* part;
+  size_t slab;            // floats per slice (c2 * ldp)
+  int nsplit, ldp, nwrow, c2;
+  float* wstar;           // [c2][nwrow] out
+  float* bstar;           // [c2] out, or NULL (no bias)
+};
+
+template <bool PARTS>
 __global__ __launch_bounds__(FPT_T) void k_fpt(const float* __restrict__ a, const float* __restrict__ b2,
                                                float* __restrict__ v_out, size_t n, FptWs w, FptPred* pred,
                                                effq_fp_state* st, double lo, double hi, double d, int levels, double tol,
-                                               int max_iter) {
+                                               int max_iter, const FptParts pp) {
   __builtin_amdgcn_s_setprio(2);   // ADMM chain (critical path) over the loss / inverse streams
   __shared__ FptSmem sm;
   const int tid = threadIdx.x, wg = blockIdx.x;
@@ -40,13 +52,42 @@ __global__ __launch_bounds__(FPT_T) void k_fpt(const float* __restrict__ a, cons
   float va[FPT_EPT], vb[FPT_EPT], vv[FPT_EPT];
   bool ok[FPT_EPT];
   const size_t base = (size_t)wg * FPT_WGV + tid;
+  if (PARTS) {
+    size_t off[FPT_EPT];
 #pragma unroll
-  for (int e = 0; e < FPT_EPT; ++e) {
-    const size_t i = base + (size_t)e * FPT_T;
-    const size_t ic = (i < n) ? i : (n - 1);
-    ok[e] = i < n;
-    va[e] = a[ic];
-    vb[e] = (b2 != nullptr) ? b2[ic] : 0.0f;
+    for (int e = 0; e < FPT_EPT; ++e) {
+      const size_t i = base + (size_t)e * FPT_T;
+      const unsigned ic = (unsigned)((i < n) ? i : (n - 1));
+      const unsigned r = ic / (unsigned)pp.nwrow;
+      ok[e] = i < n;
+      off[e] = (size_t)r * pp.ldp + (ic - r * (unsigned)pp.nwrow);
+      vb[e] = b2[ic];
+      va[e] = pp.part[off[e]];
+    }
+    for (int z = 1; z < pp.nsplit; ++z) {        // slice order: deterministic, k_prox_reduce4's sums
+      float t[FPT_EPT];
+#pragma unroll
+      for (int e = 0; e < FPT_EPT; ++e) t[e] = pp.part[(size_t)z * pp.slab + off[e]];
+#pragma unroll
+      for (int e = 0; e < FPT_EPT; ++e) va[e] += t[e];
+    }
+#pragma unroll
+    for (int e = 0; e < FPT_EPT; ++e)
+      if (ok[e]) pp.wstar[base + (size_t)e * FPT_T] = va[e];
+    if (wg == 0 && pp.bstar != nullptr && tid < pp.c2) {
+      float t = pp.part[(size_t)tid * pp.ldp + pp.nwrow];
+      for (int z = 1; z < pp.nsplit; ++z) t += pp.part[(size_t)z * pp.slab + (size_t)tid * pp.ldp + pp.nwrow];
+      pp.bstar[tid] = t;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < FPT_EPT; ++e) {
+      const size_t i = base + (size_t)e * FPT_T;
+      const size_t ic = (i < n) ? i : (n - 1);
+      ok[e] = i < n;
+      va[e] = a[ic];
+      vb[e] = (b2 != nullptr) ? b2[ic] : 0.0f;
+    }
   }
 #pragma unroll
   for (int e = 0; e < FPT_EPT; ++e) {
@@ -72,7 +113,7 @@ __global__ __launch_bounds__(FPT_T) void k_fpt(const float* __restrict__ a, cons
   __syncthreads();
 
   const bool vec_ok = (v_out != nullptr) && ((reinterpret_cast<uintptr_t>(v_out) & 15u) == 0);
-  fpt_phase2<FPT_CR, FPT_FC, FPT_PF>(sm, cx, w, pred, st, (v_out != nullptr) ? v_out : a, vec_ok, n, (int)gridDim.x, levels, tol, max_iter, nullptr,
+  fpt_phase2<FPT_CR, FPT_FC, FPT_PF>(sm, cx, w, pred, st, (v_out != nullptr) ? v_out : (PARTS ? pp.wstar : a), vec_ok, n, (int)gridDim.x, levels, tol, max_iter, nullptr,
              nullptr);
 }
 
@@ -98,8 +139,35 @@ int effq_fixed_point_traj(const float* a, const float* b, float* v_out, size_t n
     return EFFQ_ERR_WORKSPACE;
   }
   const double d = (hi - lo) / (double)(levels - 1);
-  hipLaunchKernelGGL(k_fpt, dim3((unsigned)fpt_groups(n)), dim3(FPT_T), 0, as_stream(stream), a, b, v_out, n,
-                     fpt_carve(ws, n), reinterpret_cast<FptPred*>(pred_dev), state_dev, lo, hi, d, levels, tol, max_iter);
+  FptParts none;
+  memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(k_fpt<false>, dim3((unsigned)fpt_groups(n)), dim3(FPT_T), 0, as_stream(stream), a, b, v_out, n,
+                     fpt_carve(ws, n), reinterpret_cast<FptPred*>(pred_dev), state_dev, lo, hi, d, levels, tol, max_iter, none);
+  EFFQ_LAUNCH_CHECK();
+  return EFFQ_OK;
+}
+
+// internal (admm_run.hip): the same on the K slices of the prox product (effq_prox_solve_prebuilt_parts): w* = their sum is
+// written to wstar_out ([c2][nwrow]), b* to bstar_out, v = w* + dual to v_out
+int effq_fixed_point_traj_parts(const float* part, int nsplit, int ldp, int c2, int nwrow, int has_bias, const float* dual,
+                                float* wstar_out, float* bstar_out, float* v_out, int levels, double lo, double hi, double tol,
+                                int max_iter, effq_fp_state* state_dev, void* pred_dev, void* ws, size_t ws_bytes,
+                                void* stream) {
+  const size_t n = (size_t)c2 * (size_t)nwrow;
+  EFFQ_CHECK_ARG(part && dual && wstar_out && v_out && state_dev && pred_dev && ws && nsplit >= 1 && c2 > 0 && nwrow > 0);
+  EFFQ_CHECK_ARG(ldp >= nwrow + (has_bias ? 1 : 0) && levels >= 2 && levels <= 16 && hi > lo && max_iter > 0 && n <= FPT_MAXN);
+  EFFQ_CHECK_ARG((!has_bias || bstar_out != nullptr) && c2 <= FPT_T && v_out != wstar_out && v_out != dual);
+  if (ws_bytes < fpt_ws_bytes(n)) {
+    set_error("fixed_point_traj: workspace %zu < %zu bytes", ws_bytes, fpt_ws_bytes(n));
+    return EFFQ_ERR_WORKSPACE;
+  }
+  FptParts pp;
+  pp.part = part; pp.slab = (size_t)c2 * (size_t)ldp; pp.nsplit = nsplit; pp.ldp = ldp; pp.nwrow = nwrow; pp.c2 = c2;
+  pp.wstar = wstar_out; pp.bstar = has_bias ? bstar_out : nullptr;
+  const double d = (hi - lo) / (double)(levels - 1);
+  hipLaunchKernelGGL(k_fpt<true>, dim3((unsigned)fpt_groups(n)), dim3(FPT_T), 0, as_stream(stream),
+                     static_cast<const float*>(nullptr), dual, v_out, n, fpt_carve(ws, n),
+                     reinterpret_cast<FptPred*>(pred_dev), state_dev, lo, hi, d, levels, tol, max_iter, pp);
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
 }

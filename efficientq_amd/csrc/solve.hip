@@ -1373,7 +1373,8 @@ size_t effq_prox_ws_bytes(int c2, int n) {
 static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
                            const float* dual, int c2, int n, int has_bias, double rho, double eta, double shift,
                            int nterms, float* wstar, float* bstar, void* ws, size_t ws_bytes, void* stream,
-                           bool prebuilt = false) {
+                           bool prebuilt = false, const float** part_out = nullptr, int* nsplit_out = nullptr,
+                           int* ldp_out = nullptr) {
   EFFQ_CHECK_ARG(B0 && Ainv && W0 && G && dual && wstar && ws && c2 > 0 && n > 0 && nterms >= 1);
   EFFQ_CHECK_ARG(!has_bias || (b0 != nullptr && bstar != nullptr));
   if (ws_bytes < effq_prox_ws_bytes(c2, n)) {
@@ -1442,7 +1443,11 @@ static int prox_solve_impl(const float* B0, const float* Ainv, const float* W0, 
     }
 #undef EFFQ_PROX_LAUNCH
     EFFQ_LAUNCH_CHECK();
-    if (pl.nsplit > 1) {
+    if (part_out != nullptr) {                  // the caller's next kernel adds the K slices up itself
+      *part_out = (pl.nsplit > 1) ? part : nullptr;
+      *nsplit_out = pl.nsplit;
+      *ldp_out = ldb;
+    } else if (pl.nsplit > 1) {
       const int nw = n - (has_bias ? 1 : 0);
       if ((nw % 4) == 0) {
         const unsigned bx = (unsigned)((ldb / 4 + 255) / 256);
@@ -1478,6 +1483,17 @@ int effq_prox_solve_prebuilt(const float* B0, const float* Ainv, const float* W0
                              float* bstar, void* ws, size_t ws_bytes, void* stream) {
   return prox_solve_impl(B0, Ainv, W0, b0, G, dual, c2, n, has_bias, rho, eta, 0.0, 1, wstar, bstar, ws, ws_bytes,
                          stream, true);
+}
+
+// internal (admm_run.hip): the product only.  *part_out != NULL: nsplit K slices of [c2][ldp] floats that the NEXT kernel
+// adds up (effq_fixed_point_traj_parts); NULL: the product had one slice and wstar / bstar are complete
+int effq_prox_solve_prebuilt_parts(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,
+                                   const float* dual, int c2, int n, int has_bias, double rho, double eta, float* wstar,
+                                   float* bstar, void* ws, size_t ws_bytes, void* stream, const float** part_out,
+                                   int* nsplit_out, int* ldp_out) {
+  EFFQ_CHECK_ARG(part_out && nsplit_out && ldp_out);
+  return prox_solve_impl(B0, Ainv, W0, b0, G, dual, c2, n, has_bias, rho, eta, 0.0, 1, wstar, bstar, ws, ws_bytes,
+                         stream, true, part_out, nsplit_out, ldp_out);
 }
 
 int effq_prox_solve_shifted(const float* B0, const float* Ainv, const float* W0, const float* b0, const float* G,

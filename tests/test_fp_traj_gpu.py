@@ -166,3 +166,51 @@ def test_aliased_output_is_rejected(ops):
     du = dev(torch.randn(32768) * 0.01)
     with pytest.raises(EffqError):
         ops.fixed_point_traj(w, du, w, 4, ops.new_fp_state(), ops.new_fp_pred())
+
+
+@pytest.mark.parametrize("c2,nwrow,has_b,nsplit", [(64, 1728, 1, 16), (128, 3456, 1, 9), (32, 2048, 0, 3)])
+def test_k_slices_of_the_prox_product_added_up_in_the_prologue(ops, c2, nwrow, has_b, nsplit):
+    """effq_fixed_point_traj_parts (internal: what effq_admm_run calls instead of k_prox_reduce4 + effq_fixed_point_traj): the
+    K slices of the product summed in slice order inside the kernel - w*, b*, v and the scale bit-identical to the two
+    launches, cold and warm."""
+    import ctypes as C
+    from efficientq_amd.hip_ops import ADMM_TOL
+    lib = ops.lib
+    fn = lib.effq_fixed_point_traj_parts
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                   C.c_void_p]
+    gen = torch.Generator().manual_seed(c2 + nwrow)
+    ldp = ((nwrow + has_b + 31) // 32) * 32
+    n = c2 * nwrow
+    w = _clustered(n, gen).reshape(c2, nwrow)
+    du = dev(torch.randn(n, generator=gen) * 0.002)
+    pred_a, pred_b = ops.new_fp_pred(), ops.new_fp_pred()
+    for rep in range(3):                                   # cold, then warm on a drifting tensor
+        w = w * (1.0 + 2e-4 * rep) + 1e-5 * torch.randn(c2, nwrow, generator=gen)
+        full = torch.zeros(c2, ldp)
+        full[:, :nwrow] = w
+        if has_b:
+            full[:, nwrow] = torch.randn(c2, generator=gen)
+        # slices that add up to `full` in slice order only approximately - the REFERENCE is their sum in that order
+        parts = torch.randn(nsplit, c2, ldp, generator=gen) * 0.01
+        parts[0] = full - parts[1:].sum(0)
+        parts = dev(parts.contiguous())
+        acc = parts[0].clone()
+        for z in range(1, nsplit):
+            acc = acc + parts[z]
+        w_sum, b_sum = acc[:, :nwrow].contiguous().reshape(-1), (acc[:, nwrow].contiguous() if has_b else None)
+        st_a, st_b = ops.new_fp_state(), ops.new_fp_state()
+        v_a, v_b = torch.empty(n, device="cuda:0"), torch.empty(n, device="cuda:0")
+        ops.fixed_point_traj(w_sum, du, v_a, 4, st_a, pred_a)
+        ws = ops._workspace("fp_traj", lib.effq_fp_traj_ws_bytes(n))
+        wst, bst = torch.empty(n, device="cuda:0"), torch.empty(c2, device="cuda:0")
+        rc = fn(parts.data_ptr(), nsplit, ldp, c2, nwrow, has_b, du.data_ptr(), wst.data_ptr(), bst.data_ptr(), v_b.data_ptr(),
+                4, -1.0, 1.0, ADMM_TOL, 400, st_b.data_ptr(), pred_b.data_ptr(), ws.data_ptr(), ws.numel(), ops.stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(wst, w_sum) and torch.equal(v_a, v_b)
+        if has_b:
+            assert torch.equal(bst, b_sum)
+        assert ops.read_fp_state(st_a) == ops.read_fp_state(st_b)
