@@ -2,7 +2,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-pat = sys.argv[2] if len(sys.argv) > 2 else "k_admm_coop"
+pat = sys.argv[2] if len(sys.argv) > 2 else "k_fpt"
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 count = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 idx = [i for i, r in enumerate(rows) if pat in r["Kernel_Name"]]
