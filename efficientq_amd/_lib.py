@@ -166,6 +166,8 @@ SIGNATURES = {
     "conv3d_calib_step_i8s": (_I, [_P, _P, _P, _P, _GP, _P, _I, _P, _I, _I, _P, _P, _SZ, _P]),
     "effq_conv_i8_ws_bytes": (_SZ, [_GP]),
     "conv3d_calib_step_i8": (_I, [_P, _P, _P, _P, _GP, _P, _I, _P, _I, _P, _P, _SZ, _P]),
+    "effq_conv_i8_out_supported": (_I, [_GP, _I, _I]),
+    "conv3d_quant_forward_i8": (_I, [_P, _P, _P, _P, _P, _GP, _P, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "effq_conv_ws_bytes": (_SZ, [_GP]),
     "conv3d_quant_calib_step": (_I, [_P, _P, _P, _P, _P, _GP, _P, _I, _P, _P, _P, _SZ, _P]),
     "effq_adam_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _I, _SZ, _P]),

@@ -44,6 +44,10 @@ struct ConvI8Params {
   unsigned int* ticket;
   double* sqerr;
   int debug;   // profiling ablations (EFFQ_I8_DEBUG): 1 no MFMA loop, 2 no halo loads, 3 no target loads
+  // conv3d_quant_forward_i8 (k_conv3d_i8l2e<true>, k_conv3d_i8w<true>): the conv output is also STORED (fp32, NDHWC) and
+  // sqerr[1] is the attention-weighted sum (att: one weight per output voxel, or NULL = the plain sum once more)
+  float* out;
+  const float* att;
 };
 
 __global__ __launch_bounds__(256) void k_pack_weight_i8(const int8_t* __restrict__ Gq, int8_t* __restrict__ wq, int C1,
@@ -729,6 +733,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2(ConvI8Params p) {
 //  * halo: per-lane relative offsets fixed at start; tiles that touch no volume face (uniform test) skip clamps and masks;
 //  * squared errors are accumulated in fp32 within a tile (4 chains of 8 terms per plane) and added to the fp64 sum once
 //    per tile, instead of one fp64 conversion + addition per output value.
+template <bool OUT>
 __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
   constexpr int VS = 48, PADB = halo_row_pad(1);
   constexpr int NHL = (L2_NH * 2 + 255) / 256;   // 5
@@ -775,6 +780,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
     v4i h[NHL];
     float y[2][16];
     unsigned hmask;
+    long long yoff;      // (OUT) the tile's first output value of this wave's plane, relative to p.y
   };
   auto fetch = [&](int tile, Regs& R) {
     int t = tile;
@@ -804,7 +810,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
       }
       R.hmask = hm;
     }
-    const float* yb = p.y + ((((long long)n * p.OD + od0 + wid) * p.OH + oh0) * p.OW + ow0) * p.C2;
+    const long long yoff = ((((long long)n * p.OD + od0 + wid) * p.OH + oh0) * p.OW + ow0) * p.C2;
+    const float* yb = p.y + yoff;
+    R.yoff = yoff;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       R.y[0][r] = yb[yrel[r]];
@@ -815,8 +823,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
   const int hv0 = (wid * I_HH + (li >> 3)) * I_HW + (li & 7);
   const int hb0 = hv0 * VS + (wid * I_HH + (li >> 3)) * PADB + 16 * lh;
   const int hb1 = hb0 + 4 * I_HH * (I_HW * VS + PADB);
-  double l0 = 0.0;
+  double l0 = 0.0, l0w = 0.0;
   auto body = [&](int tile, Regs& X, bool more) {
+    const long long yoff_cur = X.yoff;
     lds_barrier();
     if (X.hmask == 0xffffffffu) {
 #pragma unroll
@@ -851,12 +860,33 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
       acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b, acc1, 0, 0, 0);
     }
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (OUT) {
+      float sw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      float* ob = p.out + yoff_cur;
+      const float* ab = (p.att != nullptr) ? p.att + yoff_cur / p.C2 : nullptr;
+      const long long aplane = (long long)p.OH * p.OW;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float d0 = ((float)acc0[r] * scale + bv) - ycur[0][r];
-      const float d1 = ((float)acc1[r] * scale + bv) - ycur[1][r];
-      s[r & 3] = __builtin_fmaf(d0, d0, s[r & 3]);
-      s[r & 3] = __builtin_fmaf(d1, d1, s[r & 3]);
+      for (int r = 0; r < 16; ++r) {
+        const int arel = ((r >> 2) * p.OW) + (r & 3) + 4 * lh;
+        const float o0 = (float)acc0[r] * scale + bv, o1 = (float)acc1[r] * scale + bv;
+        ob[yrel[r]] = o0;
+        ob[4 * yplane + yrel[r]] = o1;
+        const float d0 = o0 - ycur[0][r], d1 = o1 - ycur[1][r];
+        const float w0 = ab ? ab[arel] : 1.0f, w1 = ab ? ab[4 * aplane + arel] : 1.0f;
+        s[r & 3] = __builtin_fmaf(d0, d0, s[r & 3]);
+        s[r & 3] = __builtin_fmaf(d1, d1, s[r & 3]);
+        sw[r & 3] = __builtin_fmaf(w0 * d0, d0, sw[r & 3]);
+        sw[r & 3] = __builtin_fmaf(w1 * d1, d1, sw[r & 3]);
+      }
+      l0w += (double)((sw[0] + sw[1]) + (sw[2] + sw[3]));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d0 = ((float)acc0[r] * scale + bv) - ycur[0][r];
+        const float d1 = ((float)acc1[r] * scale + bv) - ycur[1][r];
+        s[r & 3] = __builtin_fmaf(d0, d0, s[r & 3]);
+        s[r & 3] = __builtin_fmaf(d1, d1, s[r & 3]);
+      }
     }
     l0 += (double)((s[0] + s[1]) + (s[2] + s[3]));
   };
@@ -869,13 +899,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) A.y[pl][r] = B.y[pl][r] = 0.0f;
   A.hmask = B.hmask = 0;
+  A.yoff = B.yoff = 0;
   if (t_begin < t_end) fetch(t_begin, A);
   if (t_begin + 1 < t_end) fetch(t_begin + 1, B);
   for (int tile = t_begin; tile < t_end; tile += 2) {
     body(tile, A, tile + 2 < t_end);
     if (tile + 1 < t_end) body(tile + 1, B, tile + 3 < t_end);
   }
-  double v[2] = {l0, l0};
+  double v[2] = {l0, OUT ? l0w : l0};
   grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.y * gridDim.x + blockIdx.x,
                      gridDim.x * gridDim.y);
 }
@@ -890,6 +921,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_i8l2e(ConvI8Params p) {
 // Tile-divisible volumes only (every shape of the shipped recipes); other shapes keep k_conv3d_i8<2>.
 constexpr int W64_WLB = 27 * 2 * 2 * 64 * 16;                                  // 110592 bytes of weights
 constexpr int W64_VS = 80, W64_HALOB = I_NH * W64_VS + I_HD * I_HH * halo_row_pad(2);
+template <bool OUT>
 __global__ __launch_bounds__(512, 1) void k_conv3d_i8w(ConvI8Params p) {
   constexpr int VS = W64_VS, PADB = halo_row_pad(2);
   constexpr int NSLOT = I_NH * 4;                   // 16-byte pieces of the halo tile (64 channels = 4 pieces)
@@ -935,6 +967,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3d_i8w(ConvI8Params p) {
     v4i h[NHL];
     float y[16];
     unsigned hmask;
+    long long yoff;      // (OUT) the tile's first output value of this wave's plane, relative to p.y
   };
   auto fetch = [&](int tile, Regs& R) {
     int t = tile;
@@ -964,7 +997,9 @@ __global__ __launch_bounds__(512, 1) void k_conv3d_i8w(ConvI8Params p) {
       }
       R.hmask = hm;
     }
-    const float* yb = p.y + ((((long long)n * p.OD + od0 + plane) * p.OH + oh0) * p.OW + ow0) * p.C2;
+    const long long yoff = ((((long long)n * p.OD + od0 + plane) * p.OH + oh0) * p.OW + ow0) * p.C2;
+    const float* yb = p.y + yoff;
+    R.yoff = yoff;
 #pragma unroll
     for (int r = 0; r < 16; ++r) R.y[r] = yb[yrel[r]];
   };
@@ -972,8 +1007,9 @@ __global__ __launch_bounds__(512, 1) void k_conv3d_i8w(ConvI8Params p) {
   const int hrow = plane * I_HH + (li >> 3);
   const int hb0 = (hrow * I_HW + (li & 7)) * VS + hrow * PADB + 16 * lh;
   const int8_t* wlane = wl + ((size_t)lh * 64 + och + li) * 16;        // + (tap * 2 + g) * 2 * 64 * 16 per step
-  double l0 = 0.0;
+  double l0 = 0.0, l0w = 0.0;
   auto body = [&](int tile, Regs& X, bool more) {
+    const long long yoff_cur = X.yoff;
     lds_barrier();
     if (X.hmask == 0xffffffffu) {
 #pragma unroll
@@ -1007,10 +1043,28 @@ __global__ __launch_bounds__(512, 1) void k_conv3d_i8w(ConvI8Params p) {
       acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc1, 0, 0, 0);
     }
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (OUT) {
+      float sw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      float* ob = p.out + yoff_cur;
+      const float* ab = (p.att != nullptr) ? p.att + yoff_cur / p.C2 : nullptr;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float d = ((float)(acc0[r] + acc1[r]) * scale + bv) - ycur[r];
-      s[r & 3] = __builtin_fmaf(d, d, s[r & 3]);
+      for (int r = 0; r < 16; ++r) {
+        const int arel = ((r >> 2) * p.OW) + (r & 3) + 4 * lh;
+        const float o = (float)(acc0[r] + acc1[r]) * scale + bv;
+        ob[yrel[r]] = o;
+        const float d = o - ycur[r];
+        // (both channel halves of a voxel add its weighted error: the sum runs over the values, as the plain one)
+        const float wgt = ab ? ab[arel] : 1.0f;
+        s[r & 3] = __builtin_fmaf(d, d, s[r & 3]);
+        sw[r & 3] = __builtin_fmaf(wgt * d, d, sw[r & 3]);
+      }
+      l0w += (double)((sw[0] + sw[1]) + (sw[2] + sw[3]));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = ((float)(acc0[r] + acc1[r]) * scale + bv) - ycur[r];
+        s[r & 3] = __builtin_fmaf(d, d, s[r & 3]);
+      }
     }
     l0 += (double)((s[0] + s[1]) + (s[2] + s[3]));
   };
@@ -1021,13 +1075,14 @@ __global__ __launch_bounds__(512, 1) void k_conv3d_i8w(ConvI8Params p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) A.y[r] = B.y[r] = 0.0f;
   A.hmask = B.hmask = 0;
+  A.yoff = B.yoff = 0;
   if (t_begin < t_end) fetch(t_begin, A);
   if (t_begin + 1 < t_end) fetch(t_begin + 1, B);
   for (int tile = t_begin; tile < t_end; tile += 2) {
     body(tile, A, tile + 2 < t_end);
     if (tile + 1 < t_end) body(tile + 1, B, tile + 3 < t_end);
   }
-  double v[2] = {l0, l0};
+  double v[2] = {l0, OUT ? l0w : l0};
   grid_sum_finish<2>(v, p.partials, p.ticket, p.sqerr, red_smem, &s_last, blockIdx.x, gridDim.x);
 }
 
@@ -1115,10 +1170,27 @@ size_t effq_conv_i8_ws_bytes(const effq_geom* g) {
   return 256 + pl.nblk * 2 * sizeof(double) + pl.wq_bytes + 256;
 }
 
-int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const float* bias, const float* y_fp,
-                         const effq_geom* g, const float* act_alpha_dev, int act_levels,
-                         const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, void* ws, size_t ws_bytes,
-                         void* stream) {
+// which of the kernels that can also store their output serves the shape: 1 = k_conv3d_i8l2e (32 -> 32), 2 = k_conv3d_i8w
+// (64 -> 64), 0 = none
+static int i8_out_kernel(const ConvI8Params& p) {
+  static const bool fast_off = getenv("EFFQ_I8L2E") != nullptr && atoi(getenv("EFFQ_I8L2E")) == 0;
+  static const bool w64_off = getenv("EFFQ_I8W") != nullptr && atoi(getenv("EFFQ_I8W")) == 0;
+  if (p.C1 == 32 && p.C2 == 32 && !fast_off && p.OD % L2_TD == 0 && p.OH % ITH == 0 && p.OW % ITW == 0) return 1;
+  if (p.C1 == 64 && p.C2 == 64 && !w64_off && !i8_stream64() && p.OD % ITD == 0 && p.OH % ITH == 0 && p.OW % ITW == 0) return 2;
+  return 0;
+}
+
+int effq_conv_i8_out_supported(const effq_geom* g, int act_levels, int w_levels) {
+  if (g == nullptr || !effq_conv_i8_supported(g, act_levels, w_levels)) return 0;
+  I8Plan pl;
+  if (i8_plan(g, &pl) != EFFQ_OK) return 0;
+  return i8_out_kernel(pl.p) != 0 ? 1 : 0;
+}
+
+static int conv_i8_impl(const uint8_t* xidx_ndhwc, const int8_t* Gq, const float* bias, const float* y_fp,
+                        const effq_geom* g, const float* act_alpha_dev, int act_levels,
+                        const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, void* ws, size_t ws_bytes,
+                        void* stream, float* out, const float* att) {
   EFFQ_CHECK_ARG(xidx_ndhwc && Gq && y_fp && g && act_alpha_dev && w_state_dev && sqerr_out && ws);
   EFFQ_CHECK_ARG(effq_conv_i8_supported(g, act_levels, w_levels));
   I8Plan pl;
@@ -1144,6 +1216,13 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
   p.inv_levels = 1.0 / ((double)(act_levels - 1) * (double)(w_levels - 1));
   p.sqerr = sqerr_out;
   p.debug = effq_ablate_env("EFFQ_I8_DEBUG");
+  p.out = out;
+  p.att = att;
+  const int outk = (out != nullptr) ? i8_out_kernel(p) : 0;
+  if (out != nullptr && outk == 0) {
+    set_error("conv_i8: no output-storing kernel for this shape (effq_conv_i8_out_supported)");
+    return EFFQ_ERR_ARG;
+  }
   hipStream_t st = as_stream(stream);
   // (the ticket of the last-block reduction is left at zero by the kernel that used it: the caller zero-fills
   //  the workspace once, effq_hip.h)
@@ -1155,14 +1234,19 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
     const size_t lds = (size_t)W64_WLB + W64_HALOB;
     static bool attr_set = false;
     if (!attr_set) {
-      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_i8w), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
+      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_i8w<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      EFFQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3d_i8w<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
     int gx = 256;                           // one workgroup per CU (LDS); pl.nblk = 256 partial slots
     if (gx > p.ntiles) gx = p.ntiles;
     if ((size_t)gx > pl.nblk) gx = (int)pl.nblk;
-    hipLaunchKernelGGL(k_conv3d_i8w, dim3((unsigned)gx), dim3(512), lds, st, p);
+    if (out != nullptr)
+      hipLaunchKernelGGL(k_conv3d_i8w<true>, dim3((unsigned)gx), dim3(512), lds, st, p);
+    else
+      hipLaunchKernelGGL(k_conv3d_i8w<false>, dim3((unsigned)gx), dim3(512), lds, st, p);
     EFFQ_LAUNCH_CHECK();
     return EFFQ_OK;
   }
@@ -1184,8 +1268,10 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
   }
   if (p.C1 == 32) {
     static const bool fast_off = getenv("EFFQ_I8L2E") != nullptr && atoi(getenv("EFFQ_I8L2E")) == 0;   // A/B switch
-    if (!fast_off && p.C2 == 32 && p.OD % L2_TD == 0 && p.OH % ITH == 0 && p.OW % ITW == 0)
-      hipLaunchKernelGGL(k_conv3d_i8l2e, pl.grid, dim3(256), 0, st, p);
+    if (out != nullptr)
+      hipLaunchKernelGGL(k_conv3d_i8l2e<true>, pl.grid, dim3(256), 0, st, p);
+    else if (!fast_off && p.C2 == 32 && p.OD % L2_TD == 0 && p.OH % ITH == 0 && p.OW % ITW == 0)
+      hipLaunchKernelGGL(k_conv3d_i8l2e<false>, pl.grid, dim3(256), 0, st, p);
     else
       hipLaunchKernelGGL(k_conv3d_i8l2, pl.grid, dim3(256), 0, st, p);
   } else if (p.C1 == 64 && !i8_stream64()) {
@@ -1216,6 +1302,23 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
   }
   EFFQ_LAUNCH_CHECK();
   return EFFQ_OK;
+}
+
+int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const float* bias, const float* y_fp,
+                         const effq_geom* g, const float* act_alpha_dev, int act_levels,
+                         const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, void* ws, size_t ws_bytes,
+                         void* stream) {
+  return conv_i8_impl(xidx_ndhwc, Gq, bias, y_fp, g, act_alpha_dev, act_levels, w_state_dev, w_levels, sqerr_out, ws,
+                      ws_bytes, stream, nullptr, nullptr);
+}
+
+int conv3d_quant_forward_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const float* bias, const float* y_fp,
+                            const float* att, const effq_geom* g, const float* act_alpha_dev, int act_levels,
+                            const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, float* out, void* ws,
+                            size_t ws_bytes, void* stream) {
+  EFFQ_CHECK_ARG(out != nullptr);
+  return conv_i8_impl(xidx_ndhwc, Gq, bias, y_fp, g, act_alpha_dev, act_levels, w_state_dev, w_levels, sqerr_out, ws,
+                      ws_bytes, stream, out, att);
 }
 
 }  // extern "C"

@@ -853,6 +853,35 @@ class HipOps:
                                             _ptr(ws), ws.numel(), self.stream), "conv3d_calib_step_i8")
         return sqerr
 
+    def conv_i8_out_supported(self, geom: Geom, act_levels: int, w_levels: int) -> bool:
+        return bool(self.lib.effq_conv_i8_out_supported(C.byref(geom), int(act_levels), int(w_levels)))
+
+    def conv_forward_i8(self, xidx: torch.Tensor, G: torch.Tensor, bias, geom: Geom, y_ndhwc: torch.Tensor, att,
+                        act_alpha: torch.Tensor, act_levels: int, w_state: torch.Tensor, w_levels: int):
+        """The quantised forward of a calibrated layer + its final loss on the i8 matrix cores (conv3d_quant_forward_i8):
+        `G` = alpha_w * b, the projected weights of the iterate whose fixed-point state is `w_state` (5 device doubles,
+        alpha first); returns (out NDHWC fp32, [sum err^2, sum att err^2] device doubles)."""
+        if xidx.dtype != torch.uint8:
+            raise _lib.EffqError("conv_forward_i8 wants uint8 level ids")
+        lm1 = int(w_levels) - 1
+        a32 = w_state.reshape(-1)[0].to(torch.float32)
+        # the integer numerators 2 * level - (Lw - 1) of the weights: G / f32(alpha) is b = level * d - 1 to an ulp
+        Gq = (2.0 * torch.round((self._f32(G) / a32 + 1.0) * (0.5 * lm1)) - lm1).to(torch.int8).contiguous()
+        _check_shapes(geom, xidx, Gq, bias, y_ndhwc)
+        al = self._f32(act_alpha.reshape(1))
+        y = self._f32(y_ndhwc)
+        out = torch.empty_like(y)
+        sq = torch.zeros(2, dtype=torch.float64, device=self.device)
+        att_f = self._f32(att) if att is not None else None
+        st = w_state.to(torch.float64).contiguous()
+        ws = self._workspace("conv_i8", self.lib.effq_conv_i8_ws_bytes(C.byref(geom)))
+        check(self.lib.conv3d_quant_forward_i8(_ptr(xidx), _ptr(Gq), _ptr(self._f32(bias) if bias is not None else None),
+                                               _ptr(y), _ptr(att_f), C.byref(geom), _ptr(al), int(act_levels), _ptr(st),
+                                               int(w_levels), _ptr(sq), _ptr(out), _ptr(ws), ws.numel(), self.stream),
+              "conv3d_quant_forward_i8")
+        self._keep_i8 = (Gq, st, att_f, al)           # operands of an enqueued kernel: alive until the next call
+        return out, sq
+
     # -- f3: gradients of the activation quantiser, Adam ----------------------------------------------------
     def act_quant_backward(self, x: torch.Tensor, alpha: torch.Tensor, levels: int, gq: torch.Tensor, want_gx=True):
         """(gx, galpha[device double]) of q = discretize(x/alpha, L, 0, 1)*alpha given gq (effq_act_quant_backward)."""

@@ -30,6 +30,7 @@ OVERLAP_LOSS_DEFAULT = _os.environ.get("EFFQ_OVERLAP_LOSS", "1") != "0"
 # per-iteration losses from the unweighted Gram system (effq_gram_loss) for layers with n = k^3 c1 + 1 up to this size
 GRAM_LOSS_DEFAULT = _os.environ.get("EFFQ_GRAM_LOSS", "1") != "0"
 GRAM_LOSS_MAX_N = int(_os.environ.get("EFFQ_GRAM_LOSS_MAX_N", "1729"))
+FORWARD_I8 = _os.environ.get("EFFQ_FORWARD_I8", "1") != "0"       # the calibrated layer's forward + final loss on the i8 cores
 GRAM_LOSS_I8 = _os.environ.get("EFFQ_GRAM_LOSS_I8", "1") != "0"     # wide layers: the quadratic form on the i8 matrix cores
 # ... up to this system size: measured per calibration, BraTS (n = 3457, 6913) 674 -> 657 ms with it; LiTS with its
 # 512-channel layers (n = 13825) included 2110 -> 2169 ms (5.4 ms per group of 8 iterates beside a chain that is itself
@@ -457,9 +458,19 @@ class EfficientQConvHIP(PTQConv):
         # quant-dequant is fused into the tile load, exactly as in the quantised forward.  Enqueued BEFORE the layer's
         # one device->host read, which then carries its two sums as well.
         fuse = self.q_act and not self._act_inited
-        out, fin = ops.conv_step(xn if fuse else xq, best_G, best_b, geom, yn, att,
-                                 act_alpha=self.alpha_act.data if fuse else None,
-                                 act_levels=self.qlvl_act if fuse else 0, want_out=True)
+        # ... on the i8 matrix cores where the level ids of the input are at hand and the shape has a kernel (32 -> 32 and
+        # 64 -> 64 channels at 3^3: the layers with the most voxels): an exact integer contraction + one multiply-add per
+        # output, HBM-bound, instead of the f32 conv (2.6 -> 0.3 ms at 16 x 64^3 voxels)
+        fwd_i8 = bool(FORWARD_I8 and fuse and xidx is not None and self.lwq_exact_int and
+                      getattr(ops, "conv_i8_out_supported", lambda *a: False)(geom, self.qlvl_act, self.qlvl_w))
+        if fwd_i8:
+            st_best = run.state_ring.index_select(0, best[1:2].to(torch.long)).reshape(-1)    # the best iterate's scale
+            out, fin = ops.conv_forward_i8(xidx, best_G, best_b, geom, yn, att, self.alpha_act.data, self.qlvl_act,
+                                           st_best, self.qlvl_w)
+        else:
+            out, fin = ops.conv_step(xn if fuse else xq, best_G, best_b, geom, yn, att,
+                                     act_alpha=self.alpha_act.data if fuse else None,
+                                     act_levels=self.qlvl_act if fuse else 0, want_out=True)
         self._ptq_out = out if (fuse or not self.q_act) else None
         red(fin)
         info = ops.admm_read(run, best, extra=fin)                         # ONE host sync for the loop and the final loss

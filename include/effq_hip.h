@@ -365,6 +365,17 @@ int conv3d_calib_step_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const floa
                          const effq_geom* g, const float* act_alpha_dev, int act_levels,
                          const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, void* ws,
                          size_t ws_bytes, void* stream);
+/* The quantised FORWARD of a calibrated layer on the same kernels (PTQConv.py:160-167 with quantised input and weights,
+ * and the final loss of EfficientQConv.py:161-166 from the same pass): out (fp32, NDHWC) = the conv output, sqerr_out[0] =
+ * sum (out - y)^2, sqerr_out[1] = sum att * (out - y)^2 (att: one weight per output voxel, [N][OD][OH][OW], or NULL: the
+ * plain sum).  An exact integer contraction and ONE fp32 multiply-add per output instead of c1 k^3 fp32 products: what
+ * the f32 conv of conv3d_quant_calib_step computes, without its rounding.  32 -> 32 and 64 -> 64 channels on volumes the
+ * kernels' tiles divide (effq_conv_i8_out_supported); ws as for conv3d_calib_step_i8. */
+int effq_conv_i8_out_supported(const effq_geom* g, int act_levels, int w_levels);
+int conv3d_quant_forward_i8(const uint8_t* xidx_ndhwc, const int8_t* Gq, const float* bias, const float* y_fp,
+                            const float* att, const effq_geom* g, const float* act_alpha_dev, int act_levels,
+                            const effq_fp_state* w_state_dev, int w_levels, double* sqerr_out, float* out, void* ws,
+                            size_t ws_bytes, void* stream);
 
 /* The same exact-integer loss for the layers the tiled kernels above do not take: few taps*channels
  * (KD*KH*KW*C1 <= 256 with C1 == 4 or C1 % 16 == 0: the first conv, the 1x1x1 convs, the classifier), any

@@ -473,6 +473,55 @@ def test_exact_int_conv_step_equals_fp32_path(ops, c1, c2, La, Lw, sp):
     assert sq8b.cpu().tolist() == s8
 
 
+@pytest.mark.parametrize("c,sp,La,Lw,with_att,with_bias", [(32, (8, 4, 8), 4, 4, True, True), (32, (24, 12, 24), 4, 4, False, True),
+                                                         (32, (16, 8, 16), 16, 16, True, False), (64, (4, 4, 8), 4, 4, True, True),
+                                                         (64, (12, 12, 24), 4, 4, True, True), (64, (8, 8, 8), 16, 16, False, False)])
+def test_quantised_forward_on_the_i8_matrix_cores(ops, c, sp, La, Lw, with_att, with_bias):
+    """conv3d_quant_forward_i8 (the calibrated layer's forward + final loss from one exact integer pass) against the f32
+    conv on the same quantised operands (conv3d_quant_calib_step with want_out) and against fp64: output, plain and
+    attention-weighted sums; the weight numerators are recovered from G and the iterate's scale."""
+    from efficientq_amd.hip_ops import make_geom
+    gen = torch.Generator().manual_seed(c + La + sp[0])
+    N = 2
+    x = torch.relu(torch.randn(N, *sp, c, generator=gen))
+    geom = make_geom((N, c, *sp), c, 3, 1, 1)
+    assert ops.conv_i8_out_supported(geom, La, Lw)
+    a_act, _, st_a = ops.fit_scale(dev(x), La, 0.0, 1.0)
+    xq, _, xidx = ops.quant_dequant_f64path(dev(x), st_a, La, 0.0, 1.0, want_idx=True)
+    alpha_act = torch.tensor(a_act, dtype=torch.float32, device="cuda:0")
+    wst = dev(torch.randn(c, c, 3, 3, 3, generator=gen) * 0.05)
+    dual, v, st_w = torch.zeros_like(wst), torch.empty_like(wst), ops.new_fp_state()
+    ops.weight_fixed_point(wst, dual, v, Lw, st_w)
+    G = torch.empty_like(wst)
+    Gq = torch.empty(wst.shape, dtype=torch.int8, device="cuda:0")
+    ops.admm_project_dual(v, wst, st_w, Lw, G, dual, 1.0, Gq)
+    b = dev(torch.randn(c, generator=gen) * 0.1) if with_bias else None
+    y = dev(torch.randn(N, *sp, c, generator=gen))
+    att = dev(torch.tensor([0.25, 1.0, 3.5])[torch.randint(0, 3, (N, *sp), generator=gen)]) if with_att else None
+    out32, sq32 = ops.conv_step(xq, G, b, geom, y, att, want_out=True)
+    out8, sq8 = ops.conv_forward_i8(xidx, G, b, geom, y, att, alpha_act, La, st_w, Lw)
+    torch.cuda.synchronize()
+    assert torch.equal(ops._keep_i8[0].reshape(Gq.shape), Gq)          # the numerators, recovered from G / alpha
+    scale = out32.abs().max().item()
+    assert (out8 - out32).abs().max().item() <= 3e-6 * scale
+    s32, s8 = sq32.cpu().tolist(), sq8.cpu().tolist()
+    assert abs(s8[0] - s32[0]) <= 2e-6 * s32[0] and abs(s8[1] - s32[1]) <= 2e-6 * s32[1], (s8, s32)
+    if not with_att:
+        assert abs(s8[1] - s8[0]) <= 1e-7 * s8[0]           # two fp32 chains of the same terms
+    # fp64 ground truth of the integer model
+    a_w = ops.read_fp_state(st_w)[0]
+    ref = torch.nn.functional.conv3d(xidx.cpu().permute(0, 4, 1, 2, 3).double(), Gq.cpu().double(), None, 1, 1)
+    ref = ref * (float(np.float32(a_act)) * float(np.float32(a_w)) / ((La - 1) * (Lw - 1)))
+    if with_bias:
+        ref = ref + b.cpu().double().view(1, -1, 1, 1, 1)
+    assert (out8.cpu().permute(0, 4, 1, 2, 3).double() - ref).abs().max().item() <= 3e-7 * scale
+    err2 = (ref - y.cpu().permute(0, 4, 1, 2, 3).double()) ** 2
+    assert abs(s8[0] - err2.sum().item()) <= 1e-6 * err2.sum().item()
+    if with_att:
+        want = (att.cpu().double().unsqueeze(1) * err2).sum().item()
+        assert abs(s8[1] - want) <= 1e-6 * want
+
+
 @pytest.mark.parametrize("c1,c2,k,pad,sp,La,Lw,att_kind,with_bias", [
     (32, 32, 3, 1, (8, 8, 16), 4, 4, "none", True), (32, 32, 3, 1, (9, 7, 11), 4, 4, "classes0", True),
     (64, 64, 3, 1, (8, 8, 8), 16, 16, "classes", False), (32, 64, 1, 0, (6, 5, 7), 4, 4, "classes", True),

@@ -876,7 +876,12 @@ def test_quantised_sliding_window_inference_and_dice_proxy(gold, monkeypatch):
         whole = torch.stack(list(model(vols)))
         one = E.sliding_window_forward(model, vols, S, 0)
         assert torch.equal(one, whole)
-        assert torch.allclose(whole[-1], res["output_q"][-1], atol=1e-5)
+        # the calibration hands each layer the output of its i8 forward (an exact integer contraction), the calibrated
+        # model runs the f32 conv: the same numbers to fp32 rounding, and a level of a later activation may flip on it
+        dq = (whole[-1] - res["output_q"][-1]).abs()
+        topq = res["output_q"][-1].abs().max().item()
+        print(f"quantised forward vs the calibration's own output: max {dq.max().item() / topq:.2e}, mean {dq.mean().item() / topq:.2e} of the largest logit")
+        assert dq.mean().item() <= 1e-6 * topq and (dq > 1e-4 * topq).float().mean().item() <= 1e-4
         sw = E.sliding_window_forward(model, vols, psz, ov)
     assert sw.shape == whole.shape and torch.isfinite(sw).all()
     dice_q, out_q, out_fp = E.fp_vs_quantised_dice(model, vols, "lits", fp_model=fp_model, patch_size=S, overlap=0)
